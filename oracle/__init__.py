@@ -1,0 +1,175 @@
+"""CPU oracle for the nvdiffrast hot path -- TEST INFRASTRUCTURE ONLY.
+
+numpy front-end over ``libnvdr_oracle.so`` (C restatement of the reference's
+algorithms, see ``nvdr_oracle.h`` for the file:line citations).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; the product path (``nvdiffrast_amd``) never does.
+
+Parity status: pinned bit-for-bit against the reference's only golden
+(``docs/img/tri.png`` -> ``tests/golden/tri.png``); everything else is
+"parity unpinned" (the reference is CUDA-only and has no tests).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libnvdr_oracle.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (a few seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not force and os.path.exists(_LIB_PATH):
+        if os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+            return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def num_threads():
+    return int(lib().nvdro_num_threads())
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _pad8(x):
+    return (x + 7) & ~7
+
+
+# --------------------------------------------------------------------------- rasterize
+
+def _raster_args(pos, tri, ranges):
+    pos = _f32(pos)
+    tri = _i32(tri)
+    instance = pos.ndim == 3
+    if instance:
+        N, V = pos.shape[0], pos.shape[1]
+        rng = None
+    else:
+        assert ranges is not None, "range mode needs ranges"
+        rng = _i32(ranges)
+        N, V = rng.shape[0], pos.shape[0]
+    return pos, tri, rng, instance, N, V, tri.shape[0]
+
+
+def rasterize(pos, tri, resolution, ranges=None, peel_depth=None, return_depth=False):
+    """-> (rast [N,H,W,4], rast_db [N,H,W,4][, depth u32 [N,Hp,Wp]]).
+
+    ``peel_depth``: previous layer's depth surface (enables the peel test)."""
+    pos, tri, rng, inst, N, V, T = _raster_args(pos, tri, ranges)
+    H, W = int(resolution[0]), int(resolution[1])
+    out = np.empty((N, H, W, 4), np.float32)
+    out_db = np.empty((N, H, W, 4), np.float32)
+    depth = np.empty((N, _pad8(H), _pad8(W)), np.uint32)
+    peel = None if peel_depth is None else np.ascontiguousarray(peel_depth, np.uint32)
+    rc = lib().nvdro_rasterize_fwd(_p(pos, _f32p), _p(tri, _i32p), _p(rng, _i32p), int(inst),
+                                   N, V, T, H, W, int(peel is not None), _p(peel, _u32p),
+                                   _p(depth, _u32p), _p(out, _f32p), _p(out_db, _f32p))
+    assert rc == 0
+    return (out, out_db, depth) if return_depth else (out, out_db)
+
+
+def rasterize_ids(pos, tri, resolution, ranges=None, peel_depth=None):
+    """Integer stage only -> (ids u32 [N,Hp,Wp], depth u32 [N,Hp,Wp])."""
+    pos, tri, rng, inst, N, V, T = _raster_args(pos, tri, ranges)
+    H, W = int(resolution[0]), int(resolution[1])
+    ids = np.empty((N, _pad8(H), _pad8(W)), np.uint32)
+    depth = np.empty((N, _pad8(H), _pad8(W)), np.uint32)
+    peel = None if peel_depth is None else np.ascontiguousarray(peel_depth, np.uint32)
+    rc = lib().nvdro_rasterize_ids(_p(pos, _f32p), _p(tri, _i32p), _p(rng, _i32p), int(inst),
+                                   N, V, T, H, W, int(peel is not None), _p(peel, _u32p),
+                                   _p(depth, _u32p), _p(ids, _u32p))
+    assert rc == 0
+    return ids, depth
+
+
+def rasterize_grad(pos, tri, rast, dy, ddb=None):
+    pos = _f32(pos); tri = _i32(tri); rast = _f32(rast); dy = _f32(dy)
+    ddb = None if ddb is None else _f32(ddb)
+    inst = pos.ndim == 3
+    N, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+    V = pos.shape[1] if inst else pos.shape[0]
+    g = np.empty_like(pos)
+    rc = lib().nvdro_rasterize_grad(_p(pos, _f32p), _p(tri, _i32p), _p(rast, _f32p), _p(dy, _f32p),
+                                    _p(ddb, _f32p), int(inst), N, V, tri.shape[0], H, W, _p(g, _f32p))
+    assert rc == 0
+    return g
+
+
+# --------------------------------------------------------------------------- interpolate
+
+def _diff_args(diff_attrs, A):
+    if diff_attrs is None or (not isinstance(diff_attrs, str) and len(diff_attrs) == 0):
+        return 0, None, 0
+    if isinstance(diff_attrs, str):
+        assert diff_attrs == "all"
+        return 1, None, A
+    lst = _i32(np.asarray(diff_attrs).reshape(-1))
+    return 0, lst, int(lst.shape[0])
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    attr = _f32(attr); rast = _f32(rast); tri = _i32(tri)
+    inst = attr.ndim == 3
+    Nattr = attr.shape[0] if inst else 1
+    V, A = attr.shape[-2], attr.shape[-1]
+    N, H, W = rast.shape[:3]
+    diff_all, lst, D = _diff_args(diff_attrs, A)
+    rdb = _f32(rast_db) if D > 0 else None
+    out = np.empty((N, H, W, A), np.float32)
+    out_da = np.empty((N, H, W, 2 * D), np.float32)
+    rc = lib().nvdro_interpolate_fwd(_p(attr, _f32p), _p(rast, _f32p), _p(tri, _i32p), _p(rdb, _f32p),
+                                     int(inst), Nattr, N, V, A, tri.shape[0], H, W,
+                                     diff_all, _p(lst, _i32p), 0 if lst is None else int(lst.shape[0]),
+                                     _p(out, _f32p), _p(out_da, _f32p) if D > 0 else None)
+    assert rc == 0
+    return out, out_da
+
+
+def interpolate_grad(attr, rast, tri, dy, rast_db=None, dda=None, diff_attrs=None):
+    """-> (g_attr, g_rast, g_rast_db or None)"""
+    attr = _f32(attr); rast = _f32(rast); tri = _i32(tri); dy = _f32(dy)
+    inst = attr.ndim == 3
+    Nattr = attr.shape[0] if inst else 1
+    V, A = attr.shape[-2], attr.shape[-1]
+    N, H, W = rast.shape[:3]
+    diff_all, lst, D = _diff_args(diff_attrs, A)
+    rdb = _f32(rast_db) if D > 0 else None
+    dda_ = _f32(dda) if D > 0 else None
+    g_attr = np.empty_like(attr)
+    g_rast = np.empty_like(rast)
+    g_rdb = np.empty_like(rast) if D > 0 else None
+    rc = lib().nvdro_interpolate_grad(_p(attr, _f32p), _p(rast, _f32p), _p(tri, _i32p), _p(dy, _f32p),
+                                      _p(rdb, _f32p), _p(dda_, _f32p), int(inst), Nattr,
+                                      N, V, A, tri.shape[0], H, W,
+                                      diff_all, _p(lst, _i32p), 0 if lst is None else int(lst.shape[0]),
+                                      _p(g_attr, _f32p), _p(g_rast, _f32p), _p(g_rdb, _f32p))
+    assert rc == 0
+    return g_attr, g_rast, g_rdb
