@@ -1,0 +1,77 @@
+"""ctypes binding of the C ABI declared in include/nvdr_hip.h.
+
+The HIP library is the ONLY compute backend of this package.  If it is missing or a
+call fails this module raises; there is no CPU or eager fallback anywhere.
+"""
+import ctypes
+import os
+
+from . import _build
+
+_lib = None
+
+c_void_p, c_int, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header.
+SIGNATURES = {
+    "nvdr_last_error": (ctypes.c_char_p, []),
+    "nvdr_abi_version": (c_int, []),
+    "nvdr_profile_enable": (None, [c_int]),
+    "nvdr_profile_reset": (None, []),
+    "nvdr_profile_read": (c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), c_int]),
+    "nvdr_rasterize_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "nvdr_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "nvdr_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nvdr_interpolate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nvdr_interpolate_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libnvdr_hip.so (never builds implicitly on a GPU box: the .so ships in-tree)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"nvdiffrast_amd: native library {path} is missing. Build it with "
+            f"`python -m nvdiffrast_amd._build` (needs hipcc); there is no fallback path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().nvdr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}(): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def profile_read(cap=64):
+    lib = load()
+    names = (ctypes.c_char_p * cap)()
+    total = (ctypes.c_double * cap)()
+    cnt = (c_int * cap)()
+    n = lib.nvdr_profile_read(names, total, cnt, cap)
+    return {names[i].decode(): (total[i], cnt[i]) for i in range(n)}

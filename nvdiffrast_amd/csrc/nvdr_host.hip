@@ -1,0 +1,82 @@
+// nvdr_host.hip -- error string, ABI version and the optional kernel timers.
+#include "nvdr_host.hpp"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace nvdr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Timed { const char* name; hipEvent_t a, b; };
+static bool g_prof = false;
+static std::mutex g_mu;
+static std::vector<Timed> g_pending;
+static std::vector<hipEvent_t> g_pool;
+static thread_local Timed g_cur;
+
+bool profile_on() { return g_prof; }
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void profile_begin(const char* name, hipStream_t s) {
+    std::lock_guard<std::mutex> l(g_mu);
+    g_cur.name = name; g_cur.a = get_event(); g_cur.b = get_event();
+    (void)hipEventRecord(g_cur.a, s);
+}
+
+void profile_end(hipStream_t s) {
+    std::lock_guard<std::mutex> l(g_mu);
+    (void)hipEventRecord(g_cur.b, s);
+    g_pending.push_back(g_cur);
+}
+
+}  // namespace nvdr
+
+extern "C" {
+
+const char* nvdr_last_error(void) { return nvdr::g_err; }
+int nvdr_abi_version(void) { return 1; }
+
+void nvdr_profile_enable(int on) { nvdr::g_prof = on != 0; }
+
+void nvdr_profile_reset(void) {
+    std::lock_guard<std::mutex> l(nvdr::g_mu);
+    for (auto& t : nvdr::g_pending) { nvdr::g_pool.push_back(t.a); nvdr::g_pool.push_back(t.b); }
+    nvdr::g_pending.clear();
+}
+
+int nvdr_profile_read(const char** names, double* total_ms, int* launches, int cap) {
+    std::lock_guard<std::mutex> l(nvdr::g_mu);
+    std::map<std::string, std::pair<const char*, std::pair<double, int>>> acc;
+    std::vector<std::string> order;
+    for (auto& t : nvdr::g_pending) {
+        (void)hipEventSynchronize(t.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t.a, t.b);
+        auto it = acc.find(t.name);
+        if (it == acc.end()) { acc[t.name] = {t.name, {0.0, 0}}; order.push_back(t.name); it = acc.find(t.name); }
+        it->second.second.first += ms;
+        it->second.second.second += 1;
+    }
+    int n = 0;
+    for (auto& k : order) {
+        if (n >= cap) break;
+        names[n] = acc[k].first; total_ms[n] = acc[k].second.first; launches[n] = acc[k].second.second; n++;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// nvdr_host.hpp -- host-side plumbing shared by the C-ABI entry points.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/nvdr_hip.h"
+
+namespace nvdr {
+
+void set_error(const char* fmt, ...);
+
+// Optional per-kernel hipEvent timing (bench.py only).
+bool profile_on();
+void profile_begin(const char* name, hipStream_t s);
+void profile_end(hipStream_t s);
+
+struct ProfileScope {
+    hipStream_t s; bool on;
+    ProfileScope(const char* name, hipStream_t s_) : s(s_), on(profile_on()) { if (on) profile_begin(name, s); }
+    ~ProfileScope() { if (on) profile_end(s); }
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace nvdr
+
+#define NVDR_REQUIRE(cond, ...)                                         \
+    do { if (!(cond)) { nvdr::set_error(__VA_ARGS__); return NVDR_ERR_ARG; } } while (0)
+
+#define NVDR_HIP_CHECK(expr)                                                            \
+    do { hipError_t e_ = (expr); if (e_ != hipSuccess) {                                \
+        nvdr::set_error("HIP error: %s (%s)", hipGetErrorString(e_), #expr);            \
+        return NVDR_ERR_LAUNCH; } } while (0)
+
+#define NVDR_LAUNCH_CHECK()  NVDR_HIP_CHECK(hipGetLastError())

@@ -1,0 +1,813 @@
+// raster.hip -- rasterize forward / backward for gfx950 (MI355X).
+//
+// Replaces, behind the C ABI of include/nvdr_hip.h, the reference's CudaRaster pipeline
+// (csrc/common/cudaraster/impl/{TriangleSetup,BinRaster,CoarseRaster,FineRaster}.inl),
+// its pixel shader and its gradient kernels (csrc/common/rasterize.cu).  The integer
+// rules (snap, cull, fill rule, U32 depth plane, visibility) are the reference's; the
+// machinery is not:
+//
+//  k_setup   one lane per triangle: snap / cull / clip / depth-plane setup.  Emits a 64 B
+//            record per surviving (sub)triangle: three edge functions in "pixel form"
+//            E(X,Y) = C + X*A + Y*B (fill rule folded into C), the depth plane, the id
+//            and a packed tile AABB.  Clipped triangles take extra slots from a per-image
+//            pool sized for the worst case (7 sub-triangles), so nothing can overflow and
+//            the host never synchronises (the reference retries after a D2H copy,
+//            RasterImpl.cpp:174-231,367).
+//  k_fine    one workgroup (8 waves) per 64x64-pixel bin, one wave per row of eight 8x8
+//            tiles, ONE LANE PER PIXEL.  Waves scan the image's packed AABBs, compact the
+//            bin's triangles into an LDS list with ballot/mbcnt prefix sums, then each wave
+//            walks the list 64 triangles at a time: a ballot over "AABB touches tile"
+//            yields the per-tile hit mask, and every hit is evaluated by all 64 pixels at
+//            once (3 edge mads + 1 depth mad per lane).  Visibility is a per-lane running
+//            minimum of the key (depth << 32 | ~id): minimum depth wins, ties go to the
+//            highest triangle id, which is exactly what the reference's in-order LEQUAL
+//            ROP produces (FineRaster.inl:152-172,349-361) but needs no ordering, no LDS
+//            atomics and no colour/depth surface.  The winning id goes straight into the
+//            pixel shader (rasterize.cu:15-114) in the same kernel, so the id/depth
+//            surfaces never touch HBM (the depth surface is stored only for depth peeling).
+//  k_grad    rasterize.cu:119-277 with DPP-reduced, triangle-grouped atomics.
+#include "nvdr_device.hpp"
+#include "nvdr_host.hpp"
+
+namespace nvdr {
+
+constexpr int      kSpLog2    = 4;                       // Constants.hpp:14
+constexpr uint32_t kDepthMin  = 17600u;                  // Constants.hpp:70
+constexpr uint32_t kDepthMax  = 0xFFFFFFFFu - 17600u;    // Constants.hpp:71
+constexpr int      kMaxViewport = 2048;                  // Constants.hpp:13
+constexpr uint32_t kEmptyBox  = 0x000000FFu;             // txlo=255 > txhi=0
+constexpr int      kSubPerTri = 7;                       // clipper output: <= 9 verts -> <= 7 tris
+
+constexpr int kBinTiles   = 8;                           // bin = 8x8 tiles = 64x64 px
+constexpr int kFineWaves  = 8;
+constexpr int kFineThreads = kFineWaves * 64;
+constexpr int kListCap    = 512;                         // LDS triangle list capacity
+
+struct Viewport {
+    int   vpw, vph;            // viewport size in pixels (unpadded)
+    int   offx, offy;          // viewport offset inside the image (multiples of 8)
+    float xs, ys, xo, yo;      // clip-space transform into the viewport tile (RasterImpl.cpp:295-298)
+};
+
+struct SetupParams {
+    const float* pos; const int* tri; const int* ranges;
+    int instance, N, V, T, maxTri, slots;
+    Viewport vp;
+    uint4* rec; uint32_t* bbox; int* poolCount;
+};
+
+// ---------------------------------------------------------------------------------
+// Triangle setup
+// ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ int cvt_rni_sat_s32(float a) {
+    // cvt.rni.sat.s32.f32 (Util.inl:31): nearest-even, clamp, NaN -> 0.
+    if (a != a) return 0;
+    a = fminf(fmaxf(a, -2147483648.0f), 2147483520.0f);
+    return (int)rintf(a);
+}
+
+__device__ __forceinline__ uint32_t cvt_rzi_u32(float a) {
+    if (!(a > 0.0f)) return 0u;
+    if (a >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)a;
+}
+
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+
+struct SubTri {
+    int px[3], py[3];
+    uint32_t zx, zy, zb;
+};
+
+// Util.inl:184-210 (setupPleq).
+__device__ void setup_depth_plane(const float zv[3], int v0x, int v0y, int d1x, int d1y, int d2x, int d2y,
+                                  float area_rcp, uint32_t& zx, uint32_t& zy, uint32_t& zb)
+{
+    float mx = fmaxf(fmaxf(zv[0], zv[1]), zv[2]);
+    int sh = min(max((__float_as_int(mx) >> 23) - (127 + 22), 0), 8);
+    int t0 = (int)(cvt_rzi_u32(zv[0]) >> sh);
+    int t1 = (int)(cvt_rzi_u32(zv[1]) >> sh) - t0;
+    int t2 = (int)(cvt_rzi_u32(zv[2]) >> sh) - t0;
+
+    uint32_t rcp_mant = ((uint32_t)__float_as_int(area_rcp) & 0x007FFFFFu) | 0x00800000u;
+    int rcp_shift = (23 + 127) - (__float_as_int(area_rcp) >> 23);
+
+    long long xc = ((long long)t1 * d2y - (long long)t2 * d1y) * (long long)rcp_mant;
+    long long yc = ((long long)t2 * d1x - (long long)t1 * d2x) * (long long)rcp_mant;
+    uint32_t px = (uint32_t)(xc >> (rcp_shift - (sh + kSpLog2)));
+    uint32_t py = (uint32_t)(yc >> (rcp_shift - (sh + kSpLog2)));
+
+    int cx = (v0x * 2 + min3i(d1x, d2x, 0) + max3i(d1x, d2x, 0)) >> (kSpLog2 + 1);
+    int cy = (v0y * 2 + min3i(d1y, d2y, 0) + max3i(d1y, d2y, 0)) >> (kSpLog2 + 1);
+    int vcx = v0x - cx * (1 << kSpLog2);
+    int vcy = v0y - cy * (1 << kSpLog2);
+
+    uint32_t pz = (uint32_t)t0 << sh;
+    pz -= (uint32_t)(((xc >> 13) * vcx + (yc >> 13) * vcy) >> (rcp_shift - (sh + 13)));
+    pz -= px * (uint32_t)cx + py * (uint32_t)cy;
+    zx = px; zy = py; zb = pz;
+}
+
+// TriangleSetup.inl:11-24, 42-116, 120-177.  Explicit fmaf = the sites nvcc contracts.
+__device__ bool snap_cull_setup(const Viewport& vp, const float (*v)[4], SubTri& st)
+{
+#pragma clang fp contract(off)
+    float vsx = (float)(vp.vpw << (kSpLog2 - 1));
+    float vsy = (float)(vp.vph << (kSpLog2 - 1));
+    float rw[3]; int px[3], py[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        rw[k] = 1.0f / v[k][3];
+        float sx = v[k][0] * rw[k]; sx = sx * vsx;
+        float sy = v[k][1] * rw[k]; sy = sy * vsy;
+        px[k] = cvt_rni_sat_s32(sx);
+        py[k] = cvt_rni_sat_s32(sy);
+    }
+    int lox = min3i(px[0], px[1], px[2]), loy = min3i(py[0], py[1], py[2]);
+    int hix = max3i(px[0], px[1], px[2]), hiy = max3i(py[0], py[1], py[2]);
+
+    int d1x = px[1] - px[0], d1y = py[1] - py[0];
+    int d2x = px[2] - px[0], d2y = py[2] - py[0];
+    int area = (int)((uint32_t)d1x * (uint32_t)d2y - (uint32_t)d1y * (uint32_t)d2x);
+    if (area == 0) return false;
+
+    const int ss = 1 << kSpLog2;
+    int bx = (vp.vpw << (kSpLog2 - 1)) - (ss >> 1);
+    int by = (vp.vph << (kSpLog2 - 1)) - (ss >> 1);
+    int alox = (lox + ss - 1 + bx) & -ss, aloy = (loy + ss - 1 + by) & -ss;
+    int ahix = (hix + bx) & -ss,          ahiy = (hiy + by) & -ss;
+    if (alox > ahix || aloy > ahiy) return false;
+
+    int diff = ahix + ahiy - alox - aloy;
+    if (diff <= ss) {
+        bool ok = false;
+        for (int pass = 0; pass < 2 && !ok; pass++) {
+            if (pass && diff == 0) break;
+            int sx = pass ? ahix : alox, sy = pass ? ahiy : aloy;
+            int t0x = px[0] + bx - sx, t0y = py[0] + by - sy;
+            int t1x = px[1] + bx - sx, t1y = py[1] + by - sy;
+            int t2x = px[2] + bx - sx, t2y = py[2] + by - sy;
+            int e0 = t0x * t1y - t0y * t1x;
+            int e1 = t1x * t2y - t1y * t2x;
+            int e2 = t2x * t0y - t2y * t0x;
+            if (area < 0) { e0 = -e0; e1 = -e1; e2 = -e2; }
+            ok = !(e0 < 0 || e1 < 0 || e2 < 0);
+        }
+        if (!ok) return false;
+    }
+
+    float vz0 = v[0][2], vz1 = v[1][2], vz2 = v[2][2];
+    float rw0 = rw[0], rw1 = rw[1], rw2 = rw[2];
+    if (area < 0) {
+        int t;
+        t = d1x; d1x = d2x; d2x = t;   t = d1y; d1y = d2y; d2y = t;
+        t = px[1]; px[1] = px[2]; px[2] = t;   t = py[1]; py[1] = py[2]; py[2] = t;
+        float f = vz1; vz1 = vz2; vz2 = f;
+        f = rw1; rw1 = rw2; rw2 = f;
+        area = -area;
+    }
+
+    const float zcoef = (float)(kDepthMax - kDepthMin) * 0.5f;
+    const float zbias = (float)(kDepthMax + kDepthMin) * 0.5f;
+    float zv[3];
+    zv[0] = __fmaf_rn(vz0 * zcoef, rw0, zbias);
+    zv[1] = __fmaf_rn(vz1 * zcoef, rw1, zbias);
+    zv[2] = __fmaf_rn(vz2 * zcoef, rw2, zbias);
+
+    int wv0x = px[0] + (vp.vpw << (kSpLog2 - 1));
+    int wv0y = py[0] + (vp.vph << (kSpLog2 - 1));
+    setup_depth_plane(zv, wv0x - (1 << (kSpLog2 - 1)), wv0y - (1 << (kSpLog2 - 1)),
+                      d1x, d1y, d2x, d2y, 1.0f / (float)area, st.zx, st.zy, st.zb);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { st.px[k] = px[k]; st.py[k] = py[k]; }
+    return true;
+}
+
+// Record layout (4 x uint4):
+//   q0 = {A0, B0, C0, A1}   q1 = {B1, C1, A2, B2}   q2 = {C2, zx, zy, zb}   q3 = {id, aabb, 0, 0}
+// with E_e(X,Y) = C_e + X*A_e + Y*B_e >= 0  <=>  pixel (X,Y) is inside edge e.
+__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id)
+{
+    const Viewport& vp = p.vp;
+    int bx = (vp.vpw - 1) << (kSpLog2 - 1);
+    int by = (vp.vph - 1) << (kSpLog2 - 1);
+    int lox = min3i(s.px[0], s.px[1], s.px[2]), hix = max3i(s.px[0], s.px[1], s.px[2]);
+    int loy = min3i(s.py[0], s.py[1], s.py[2]), hiy = max3i(s.py[0], s.py[1], s.py[2]);
+    int x0 = max((lox + bx + 15) >> 4, 0), x1 = min((hix + bx) >> 4, vp.vpw - 1);
+    int y0 = max((loy + by + 15) >> 4, 0), y1 = min((hiy + by) >> 4, vp.vph - 1);
+    size_t so = (size_t)n * p.slots + slot;
+    if (x0 > x1 || y0 > y1) { p.bbox[so] = kEmptyBox; return; }
+    uint32_t box = (uint32_t)(x0 >> 3) | ((uint32_t)(y0 >> 3) << 8) | ((uint32_t)(x1 >> 3) << 16) | ((uint32_t)(y1 >> 3) << 24);
+
+    uint32_t A[3], B[3], C[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        int a = e, b = (e + 1) % 3;
+        int dx = s.px[b] - s.px[a], dy = s.py[b] - s.py[a];
+        // E(s) = (a - s) x d with s = (16X - bx, 16Y - by); exclusive edge needs E > 0 (Util.inl:304-309).
+        uint32_t excl = (dy > 0 || (dy == 0 && dx <= 0)) ? 1u : 0u;
+        A[e] = (uint32_t)(-16 * dy);
+        B[e] = (uint32_t)(16 * dx);
+        C[e] = (uint32_t)(s.px[a] + bx) * (uint32_t)dy - (uint32_t)(s.py[a] + by) * (uint32_t)dx - excl;
+    }
+    uint4* r = p.rec + so * 4;
+    r[0] = make_uint4(A[0], B[0], C[0], A[1]);
+    r[1] = make_uint4(B[1], C[1], A[2], B[2]);
+    r[2] = make_uint4(C[2], s.zx, s.zy, s.zb);
+    r[3] = make_uint4((uint32_t)id, box, 0u, 0u);
+    p.bbox[so] = box;
+}
+
+// Util.inl:101-130.
+__device__ int clip_poly_plane(float* out, const float* in, int n_in, float f0, float f1, float f2)
+{
+#pragma clang fp contract(off)
+    int n_out = 0;
+    if (n_in >= 3) {
+        int ai = (n_in - 1) * 2;
+        float av = __fmaf_rn(f2, in[ai + 1], __fmaf_rn(f1, in[ai + 0], f0));
+        for (int bi = 0; bi < n_in * 2; bi += 2) {
+            float bv = __fmaf_rn(f2, in[bi + 1], __fmaf_rn(f1, in[bi + 0], f0));
+            if (av * bv < 0.0f) {
+                float bc = av / (av - bv);
+                float ac = 1.0f - bc;
+                out[n_out + 0] = __fmaf_rn(in[ai + 0], ac, in[bi + 0] * bc);
+                out[n_out + 1] = __fmaf_rn(in[ai + 1], ac, in[bi + 1] * bc);
+                n_out += 2;
+            }
+            if (bv >= 0.0f) {
+                out[n_out + 0] = in[bi + 0];
+                out[n_out + 1] = in[bi + 1];
+                n_out += 2;
+            }
+            ai = bi;
+            av = bv;
+        }
+    }
+    return n_out >> 1;
+}
+
+// Slow path, TriangleSetup.inl:355-434 + Util.inl:134-160.  Kept out of line so the common
+// path stays small.
+__device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id)
+{
+#pragma clang fp contract(off)
+    float d1[4], d2[4], bary[18], tmp[18];
+#pragma unroll
+    for (int c = 0; c < 4; c++) { d1[c] = v[1][c] - v[0][c]; d2[c] = v[2][c] - v[0][c]; }
+    int num = 3;
+    bary[0] = 0.f; bary[1] = 0.f; bary[2] = 1.f; bary[3] = 0.f; bary[4] = 0.f; bary[5] = 1.f;
+    for (int ax = 0; ax < 3; ax++) {
+        if ((v[0][3] < fabsf(v[0][ax])) || (v[1][3] < fabsf(v[1][ax])) || (v[2][3] < fabsf(v[2][ax]))) {
+            num = clip_poly_plane(tmp, bary, num, v[0][3] + v[0][ax], d1[3] + d1[ax], d2[3] + d2[ax]);
+            num = clip_poly_plane(bary, tmp, num, v[0][3] - v[0][ax], d1[3] - d1[ax], d2[3] - d2[ax]);
+        }
+    }
+
+    // First pass: set up the fan, remember survivors (at most 7).
+    SubTri st[kSubPerTri];
+    int ns = 0;
+    float c0[4], cp[4], cc[4];
+    for (int i = 0; i < num; i++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            cc[c] = __fmaf_rn(d2[c], bary[i * 2 + 1], __fmaf_rn(d1[c], bary[i * 2 + 0], v[0][c]));
+        if (i == 0) { for (int c = 0; c < 4; c++) c0[c] = cc[c]; }
+        else if (i >= 2) {
+            float t[3][4];
+            for (int c = 0; c < 4; c++) { t[0][c] = c0[c]; t[1][c] = cp[c]; t[2][c] = cc[c]; }
+            if (snap_cull_setup(p.vp, t, st[ns])) ns++;
+        }
+        for (int c = 0; c < 4; c++) cp[c] = cc[c];
+    }
+
+    if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return; }
+    emit_record(p, n, slot0, st[0], id);
+    if (ns > 1) {
+        int base = atomicAdd(&p.poolCount[n], ns - 1);       // cannot exceed slots - maxTri by construction
+        for (int k = 1; k < ns; k++)
+            emit_record(p, n, p.maxTri + base + k - 1, st[k], id);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_setup(const SetupParams p)
+{
+#pragma clang fp contract(off)
+    int n = blockIdx.y;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
+    if (i >= cnt) return;
+    size_t so = (size_t)n * p.slots + i;
+    int t = i + (p.instance ? 0 : p.ranges[2 * n]);
+    if ((uint32_t)t >= (uint32_t)p.T) { p.bbox[so] = kEmptyBox; return; }           // :228-233
+    uint32_t i0 = (uint32_t)p.tri[t * 3 + 0], i1 = (uint32_t)p.tri[t * 3 + 1], i2 = (uint32_t)p.tri[t * 3 + 2];
+    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) { p.bbox[so] = kEmptyBox; return; } // :241-248
+
+    const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
+    float4 q0 = vb[i0], q1 = vb[i1], q2 = vb[i2];
+    float v[3][4];
+    // Viewport-tile transform (:262-267); identity when the image is one viewport.
+    v[0][0] = __fmaf_rn(q0.x, p.vp.xs, q0.w * p.vp.xo); v[0][1] = __fmaf_rn(q0.y, p.vp.ys, q0.w * p.vp.yo); v[0][2] = q0.z; v[0][3] = q0.w;
+    v[1][0] = __fmaf_rn(q1.x, p.vp.xs, q1.w * p.vp.xo); v[1][1] = __fmaf_rn(q1.y, p.vp.ys, q1.w * p.vp.yo); v[1][2] = q1.z; v[1][3] = q1.w;
+    v[2][0] = __fmaf_rn(q2.x, p.vp.xs, q2.w * p.vp.xo); v[2][1] = __fmaf_rn(q2.y, p.vp.ys, q2.w * p.vp.yo); v[2][2] = q2.z; v[2][3] = q2.w;
+
+    // Trivial reject: all vertices beyond one frustum plane (:271-283).
+    if ((v[0][3] < fabsf(v[0][0])) || (v[0][3] < fabsf(v[0][1])) || (v[0][3] < fabsf(v[0][2]))) {
+        bool out = false;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) {
+            out |= (v[0][3] < +v[0][ax]) & (v[1][3] < +v[1][ax]) & (v[2][3] < +v[2][ax]);
+            out |= (v[0][3] < -v[0][ax]) & (v[1][3] < -v[1][ax]) & (v[2][3] < -v[2][ax]);
+        }
+        if (out) { p.bbox[so] = kEmptyBox; return; }
+    }
+
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        inside = inside && (v[k][3] >= fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fabsf(v[k][2])));
+
+    if (inside) {                                                                    // :329-352
+        SubTri st;
+        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1);
+        else p.bbox[so] = kEmptyBox;
+    } else {
+        setup_clipped(p, n, i, v, t + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Fine raster + pixel shader
+// ---------------------------------------------------------------------------------
+
+struct FineParams {
+    const uint4* rec; const uint32_t* bbox; const int* poolCount; const int* ranges;
+    const float* pos; const int* tri;
+    int instance, N, V, T, maxTri, slots;
+    int W, H, Wp, Hp;              // image size and padded surface size
+    Viewport vp;
+    int binsX, binsY, totalBins;   // bins per viewport tile, N*binsX*binsY
+    const uint32_t* peel; uint32_t* depth;
+    float* out; float* out_db;
+    float xs, xo, ys, yo;          // pixel -> clip transform of the whole image (torch_rasterize.cpp:146-149)
+};
+
+// One candidate triangle against one 8x8 tile, all 64 pixels at once.
+template <bool PEEL>
+__device__ __forceinline__ void raster_hit(const uint4* __restrict__ r, int X, int Y, uint32_t peelz, uint64_t& key)
+{
+    uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+    // Edge functions in wrapping 32-bit arithmetic; operands fit 24 bits (|A|,|B| <= 2^20, X,Y < 2^11).
+    uint32_t e0 = q0.z + (uint32_t)__mul24((int)q0.x, X) + (uint32_t)__mul24((int)q0.y, Y);
+    uint32_t e1 = q1.y + (uint32_t)__mul24((int)q0.w, X) + (uint32_t)__mul24((int)q1.x, Y);
+    uint32_t e2 = q2.x + (uint32_t)__mul24((int)q1.z, X) + (uint32_t)__mul24((int)q1.w, Y);
+    bool covered = (int)(e0 | e1 | e2) >= 0;
+    uint32_t depth = q2.y * (uint32_t)X + q2.z * (uint32_t)Y + q2.w;            // FineRaster.inl:348
+    if (PEEL) covered = covered && (depth > peelz);                             // :349
+    uint64_t k = ((uint64_t)depth << 32) | (uint32_t)~q3.x;
+    if (covered && k < key) key = k;                                            // LEQUAL in order == min key
+}
+
+template <bool PEEL, bool WRITE_DEPTH>
+__global__ __launch_bounds__(kFineThreads) void k_fine(const FineParams p)
+{
+    __shared__ uint4    s_rec[kListCap * 4];
+    __shared__ uint32_t s_box[kListCap];
+    __shared__ int      s_count;
+
+    // XCD-aware work assignment: blocks b, b+8, b+16, ... run on one XCD (observed b % 8
+    // placement) and get consecutive work items, i.e. the bins of the same image, so an
+    // image's records/AABBs/vertices stay in one L2.  Placement only affects speed.
+    const int perXcd = (p.totalBins + 7) >> 3;
+    const int work = (int)(blockIdx.x & 7) * perXcd + (int)(blockIdx.x >> 3);
+    if (work >= p.totalBins) return;
+    const int binsPerImage = p.binsX * p.binsY;
+    const int n   = work / binsPerImage;
+    const int bin = work - n * binsPerImage;
+    const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
+    const int btx0 = binX * kBinTiles, bty0 = binY * kBinTiles;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ty = bty0 + wave;                 // this wave's tile row
+    const int lx = lane & 7, ly = lane >> 3;
+    const int Y = ty * 8 + ly;                  // viewport-local pixel row
+
+    const int vpwPad = (p.vp.vpw + 7) & ~7, vphPad = (p.vp.vph + 7) & ~7;
+
+    const int direct = p.instance ? p.T : p.ranges[2 * n + 1];
+    const int pool   = min(p.poolCount[n], p.slots - p.maxTri);
+    const int total  = direct + pool;
+    const uint32_t* gbox = p.bbox + (size_t)n * p.slots;
+    const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
+
+    const uint64_t kInit = ((uint64_t)kDepthMax << 32) | 0xFFFFFFFFull;
+    uint64_t key[kBinTiles];
+    uint32_t peelz[kBinTiles];
+#pragma unroll
+    for (int t = 0; t < kBinTiles; t++) {
+        key[t] = kInit;
+        peelz[t] = 0;
+        if (PEEL) {
+            int X = (btx0 + t) * 8 + lx;
+            if (X < vpwPad && Y < vphPad)
+                peelz[t] = p.peel[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)];
+        }
+    }
+
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+
+    int scan = wave * 64;      // this wave's position in the image's slot index space
+    int skip = 0;              // hits of the current 64-slot group already listed
+    bool done = (scan >= total);
+
+    for (;;) {
+        // ---- filter: compact this bin's triangles into the LDS list ----------------
+        while (!done) {
+            int idx = scan + lane;
+            int slot = (idx < direct) ? idx : p.maxTri + (idx - direct);
+            uint32_t box = (idx < total) ? gbox[slot] : kEmptyBox;
+            int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
+            bool hit = (txlo <= btx0 + kBinTiles - 1) & (txhi >= btx0) & (tylo <= bty0 + kBinTiles - 1) & (tyhi >= bty0);
+            uint64_t m = __ballot(hit);
+            int nh = __popcll(m) - skip;
+            if (nh > 0) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_count, nh);
+                base = __builtin_amdgcn_readfirstlane(base);
+                int can = min(max(kListCap - base, 0), nh);
+                int rank = mask_rank(m) - skip;
+                if (hit && rank >= 0 && rank < can) {
+                    int dst = base + rank;
+                    const uint4* src = grec + (size_t)slot * 4;
+                    s_rec[dst * 4 + 0] = src[0];
+                    s_rec[dst * 4 + 1] = src[1];
+                    s_rec[dst * 4 + 2] = src[2];
+                    s_rec[dst * 4 + 3] = src[3];
+                    s_box[dst] = box;
+                }
+                if (can < nh) { skip += can; break; }       // list full: resume here after the flush
+            }
+            skip = 0;
+            scan += kFineThreads;
+            done = (scan >= total);
+        }
+        const int allDone = __syncthreads_and(done ? 1 : 0);
+        const int cnt = min(s_count, kListCap);
+
+        // ---- raster: 64 list entries at a time against this wave's 8 tiles ---------
+        if (ty * 8 < vphPad) {
+            for (int c = 0; c < cnt; c += 64) {
+                int j = c + lane;
+                uint32_t box = (j < cnt) ? s_box[j] : kEmptyBox;
+                int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
+                bool rowhit = (tylo <= ty) & (ty <= tyhi);
+                if (__ballot(rowhit) == 0) continue;
+#pragma unroll
+                for (int t = 0; t < kBinTiles; t++) {
+                    const int tx = btx0 + t;
+                    uint64_t m = __ballot(rowhit & (txlo <= tx) & (tx <= txhi));
+                    const int X = tx * 8 + lx;
+                    while (m) {
+                        int b = __builtin_ctzll(m);
+                        m &= m - 1;
+                        raster_hit<PEEL>(&s_rec[(c + b) * 4], X, Y, peelz[t], key[t]);
+                    }
+                }
+            }
+        }
+        if (allDone) break;
+        __syncthreads();
+        if (threadIdx.x == 0) s_count = 0;
+        __syncthreads();
+    }
+
+    // ---- pixel shader (rasterize.cu:15-114) + stores ---------------------------------
+    const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
+#pragma unroll
+    for (int t = 0; t < kBinTiles; t++) {
+        const int X = (btx0 + t) * 8 + lx;
+        if (WRITE_DEPTH) {
+            if (X < vpwPad && Y < vphPad)
+                p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key[t] >> 32);
+        }
+        if (X >= p.vp.vpw || Y >= p.vp.vph) continue;
+        const int px = X + p.vp.offx, py = Y + p.vp.offy;
+        const size_t pidx = ((size_t)n * p.H + py) * p.W + px;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f), odb = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int triIdx = (int)(~(uint32_t)key[t]) - 1;
+        bool write = true;
+        if (triIdx >= 0 && triIdx < p.T) {
+            int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
+            if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) {
+                write = false;                       // reference leaves the pixel untouched (:43-47)
+            } else {
+                float4 p0 = vb[vi0], p1 = vb[vi1], p2 = vb[vi2];
+                float fx = p.xs * (float)px + p.xo;
+                float fy = p.ys * (float)py + p.yo;
+                float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+                float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+                float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+                float a0 = p1x * p2y - p1y * p2x;
+                float a1 = p2x * p0y - p2y * p0x;
+                float a2 = p0x * p1y - p0y * p1x;
+                float iw = 1.f / (a0 + a1 + a2);
+                float b0 = a0 * iw, b1 = a1 * iw;
+                float z = p0.z * a0 + p1.z * a1 + p2.z * a2;
+                float w = p0.w * a0 + p1.w * a1 + p2.w * a2;
+                float zw = z / w;
+                b0 = __saturatef(b0); b1 = __saturatef(b1);
+                float bs = 1.f / fmaxf(b0 + b1, 1.f);
+                b0 *= bs; b1 *= bs;
+                zw = fmaxf(fminf(zw, 1.f), -1.f);
+                o = make_float4(b0, b1, zw, triidx_to_float(triIdx + 1));
+
+                float dfxdx = p.xs * iw, dfydy = p.ys * iw;
+                float da0dx = p2.y * p1.w - p1.y * p2.w, da0dy = p1.x * p2.w - p2.x * p1.w;
+                float da1dx = p0.y * p2.w - p2.y * p0.w, da1dy = p2.x * p0.w - p0.x * p2.w;
+                float da2dx = p1.y * p0.w - p0.y * p1.w, da2dy = p0.x * p1.w - p1.x * p0.w;
+                float datdx = da0dx + da1dx + da2dx, datdy = da0dy + da1dy + da2dy;
+                odb = make_float4(dfxdx * (b0 * datdx - da0dx), dfydy * (b0 * datdy - da0dy),
+                                  dfxdx * (b1 * datdx - da1dx), dfydy * (b1 * datdy - da1dy));
+            }
+        }
+        if (write) {
+            ((float4*)p.out)[pidx] = o;
+            ((float4*)p.out_db)[pidx] = odb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Backward (rasterize.cu:119-277)
+// ---------------------------------------------------------------------------------
+
+struct GradParams {
+    const float* pos; const int* tri; const float* out; const float* dy; const float* ddb;
+    float* grad;
+    int instance, N, V, T, W, H;
+    float xs, xo, ys, yo;
+};
+
+// Block = 4 waves, each wave an 8x8 pixel tile (keeps a triangle's pixels in one wave so the
+// grouped reduction collapses most of its atomics).
+template <bool ENABLE_DB>
+__global__ __launch_bounds__(256) void k_raster_grad(const GradParams p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
+    const int py = blockIdx.y * 8 + (lane >> 3);
+    const int pz = blockIdx.z;
+    bool active = (px < p.W) && (py < p.H);
+
+    int triIdx = -1, vi0 = 0, vi1 = 0, vi2 = 0;
+    float2 dy = make_float2(0.f, 0.f);
+    float4 ddb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int grad_all_ddb = 0;
+    if (active) {
+        size_t pidx = ((size_t)pz * p.H + py) * p.W + px;
+        float4 o = ((const float4*)p.out)[pidx];
+        float4 d = ((const float4*)p.dy)[pidx];
+        dy = make_float2(d.x, d.y);
+        if (ENABLE_DB) ddb = ((const float4*)p.ddb)[pidx];
+        triIdx = float_to_triidx(o.w) - 1;
+        active = (triIdx >= 0 && triIdx < p.T);
+        int grad_all_dy = __float_as_int(dy.x) | __float_as_int(dy.y);
+        if (ENABLE_DB) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
+        if ((((uint32_t)(grad_all_dy | grad_all_ddb)) << 1) == 0u) active = false;      // all +-0 (:143-148)
+    }
+    if (active) {
+        vi0 = p.tri[triIdx * 3 + 0]; vi1 = p.tri[triIdx * 3 + 1]; vi2 = p.tri[triIdx * 3 + 2];
+        if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) active = false;
+    }
+    if (__ballot(active) == 0) return;
+
+    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        if (p.instance) { vi0 += pz * p.V; vi1 += pz * p.V; vi2 += pz * p.V; }
+        float4 p0 = ((const float4*)p.pos)[vi0], p1 = ((const float4*)p.pos)[vi1], p2 = ((const float4*)p.pos)[vi2];
+        float fx = p.xs * (float)px + p.xo;
+        float fy = p.ys * (float)py + p.yo;
+        float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+        float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+        float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+        float a0 = p1x * p2y - p1y * p2x;
+        float a1 = p2x * p0y - p2y * p0x;
+        float a2 = p0x * p1y - p0y * p1x;
+
+        float at = a0 + a1 + a2;
+        float ep = copysignf(1e-6f, at);
+        float iw = 1.f / (at + ep);
+        float b0 = a0 * iw, b1 = a1 * iw;
+
+        float gb0 = dy.x * iw, gb1 = dy.y * iw;
+        float gbb = gb0 * b0 + gb1 * b1;
+        float gp0x = gbb * (p2y - p1y) - gb1 * p2y;
+        float gp1x = gbb * (p0y - p2y) + gb0 * p2y;
+        float gp2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+        float gp0y = gbb * (p1x - p2x) + gb1 * p2x;
+        float gp1y = gbb * (p2x - p0x) - gb0 * p2x;
+        float gp2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+        float gp0w = -fx * gp0x - fy * gp0y;
+        float gp1w = -fx * gp1x - fy * gp1y;
+        float gp2w = -fx * gp2x - fy * gp2y;
+
+        if (ENABLE_DB && (((uint32_t)grad_all_ddb) << 1) != 0u) {
+            float dfxdX = p.xs * iw, dfydY = p.ys * iw;
+            ddb.x *= dfxdX; ddb.y *= dfydY; ddb.z *= dfxdX; ddb.w *= dfydY;
+
+            float da0dX = p1.y * p2.w - p2.y * p1.w;
+            float da1dX = p2.y * p0.w - p0.y * p2.w;
+            float da2dX = p0.y * p1.w - p1.y * p0.w;
+            float da0dY = p2.x * p1.w - p1.x * p2.w;
+            float da1dY = p0.x * p2.w - p2.x * p0.w;
+            float da2dY = p1.x * p0.w - p0.x * p1.w;
+            float datdX = da0dX + da1dX + da2dX;
+            float datdY = da0dY + da1dY + da2dY;
+
+            float x01 = p0.x - p1.x, x12 = p1.x - p2.x, x20 = p2.x - p0.x;
+            float y01 = p0.y - p1.y, y12 = p1.y - p2.y, y20 = p2.y - p0.y;
+            float w01 = p0.w - p1.w, w12 = p1.w - p2.w, w20 = p2.w - p0.w;
+
+            float a0p1 = fy * p2.x - fx * p2.y;
+            float a0p2 = fx * p1.y - fy * p1.x;
+            float a1p0 = fx * p2.y - fy * p2.x;
+            float a1p2 = fy * p0.x - fx * p0.y;
+
+            float wdudX = 2.f * b0 * datdX - da0dX;
+            float wdudY = 2.f * b0 * datdY - da0dY;
+            float wdvdX = 2.f * b1 * datdX - da1dX;
+            float wdvdY = 2.f * b1 * datdY - da1dY;
+
+            float c0  = iw * (ddb.x * wdudX + ddb.y * wdudY + ddb.z * wdvdX + ddb.w * wdvdY);
+            float cx  = c0 * fx - ddb.x * b0 - ddb.z * b1;
+            float cy  = c0 * fy - ddb.y * b0 - ddb.w * b1;
+            float cxy = iw * (ddb.x * datdX + ddb.y * datdY);
+            float czw = iw * (ddb.z * datdX + ddb.w * datdY);
+
+            gp0x += c0 * y12 - cy * w12 + czw * p2y + ddb.w * p2.w;
+            gp1x += c0 * y20 - cy * w20 - cxy * p2y - ddb.y * p2.w;
+            gp2x += c0 * y01 - cy * w01 + cxy * p1y - czw * p0y + ddb.y * p1.w - ddb.w * p0.w;
+            gp0y += cx * w12 - c0 * x12 - czw * p2x - ddb.z * p2.w;
+            gp1y += cx * w20 - c0 * x20 + cxy * p2x + ddb.x * p2.w;
+            gp2y += cx * w01 - c0 * x01 - cxy * p1x + czw * p0x - ddb.x * p1.w + ddb.z * p0.w;
+            gp0w += cy * x12 - cx * y12 - czw * a1p0 + ddb.z * p2.y - ddb.w * p2.x;
+            gp1w += cy * x20 - cx * y20 - cxy * a0p1 - ddb.x * p2.y + ddb.y * p2.x;
+            gp2w += cy * x01 - cx * y01 - cxy * a0p2 - czw * a1p2 + ddb.x * p1.y - ddb.y * p1.x - ddb.z * p0.y + ddb.w * p0.x;
+        }
+        g[0] = gp0x; g[1] = gp0y; g[2] = gp0w;
+        g[3] = gp1x; g[4] = gp1y; g[5] = gp1w;
+        g[6] = gp2x; g[7] = gp2y; g[8] = gp2w;
+    }
+
+    // One atomic per (triangle, vertex, component) per wave instead of per pixel.
+    GroupIter it(active, triIdx);
+    while (it.next()) {
+        const int w0 = it.bcast(vi0), w1 = it.bcast(vi1), w2 = it.bcast(vi2);
+        float s[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) s[k] = it.sum(g[k]);
+        if (it.writer()) {
+            float* q0 = p.grad + (size_t)w0 * 4; float* q1 = p.grad + (size_t)w1 * 4; float* q2 = p.grad + (size_t)w2 * 4;
+            atomic_add_f32(q0 + 0, s[0]); atomic_add_f32(q0 + 1, s[1]); atomic_add_f32(q0 + 3, s[2]);
+            atomic_add_f32(q1 + 0, s[3]); atomic_add_f32(q1 + 1, s[4]); atomic_add_f32(q1 + 3, s[5]);
+            atomic_add_f32(q2 + 0, s[6]); atomic_add_f32(q2 + 1, s[7]); atomic_add_f32(q2 + 3, s[8]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------
+
+struct ScratchLayout { size_t rec, bbox, pool, total; int slots; };
+
+static ScratchLayout scratch_layout(int N, int max_tri)
+{
+    ScratchLayout L;
+    L.slots = max_tri * kSubPerTri;
+    L.rec   = 0;
+    L.bbox  = align_up(L.rec + (size_t)N * L.slots * 64, 256);
+    L.pool  = align_up(L.bbox + (size_t)N * L.slots * 4, 256);
+    L.total = align_up(L.pool + (size_t)N * 4, 256);
+    return L;
+}
+
+}  // namespace nvdr
+
+using namespace nvdr;
+
+extern "C" size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W)
+{
+    (void)H; (void)W;
+    if (N <= 0 || max_tri <= 0) return 0;
+    return scratch_layout(N, max_tri).total;
+}
+
+extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
+                                  int instance_mode, int N, int V, int T, int max_tri, int H, int W,
+                                  const uint32_t* peel_depth, uint32_t* depth_out,
+                                  void* scratch, size_t scratch_bytes,
+                                  float* out, float* out_db, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_REQUIRE(pos && tri && out && out_db && scratch, "rasterize_fwd: null pointer");
+    NVDR_REQUIRE(instance_mode || ranges, "rasterize_fwd: range mode needs ranges");
+    NVDR_REQUIRE(N > 0 && V > 0 && T > 0 && max_tri > 0, "rasterize_fwd: empty input");
+    NVDR_REQUIRE(H > 0 && W > 0, "resolution must be [>0, >0]");
+    NVDR_REQUIRE(!((uintptr_t)pos & 15), "pos input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)out & 15), "out output tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)out_db & 15), "out_db output tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)scratch & 255), "scratch must be 256-byte aligned");
+    NVDR_REQUIRE((long long)max_tri * kSubPerTri < (1ll << 31) / 4, "subtriangle count overflow");
+    ScratchLayout L = scratch_layout(N, max_tri);
+    if (scratch_bytes < L.total) { set_error("rasterize_fwd: scratch too small (%zu < %zu)", scratch_bytes, L.total); return NVDR_ERR_SCRATCH; }
+
+    char* sb = (char*)scratch;
+    uint4* rec = (uint4*)(sb + L.rec);
+    uint32_t* bbox = (uint32_t*)(sb + L.bbox);
+    int* pool = (int*)(sb + L.pool);
+
+    const int Hp = (H + 7) & ~7, Wp = (W + 7) & ~7;
+    // Viewport tiling for images beyond 2048 px (torch_rasterize.cpp:99-124).
+    const int tcx = (Wp + kMaxViewport - 1) / kMaxViewport, tcy = (Hp + kMaxViewport - 1) / kMaxViewport;
+    const int tsx = ((Wp + tcx - 1) / tcx + 7) & ~7, tsy = ((Hp + tcy - 1) / tcy + 7) & ~7;
+
+    for (int ty = 0; ty < tcy; ty++)
+    for (int tx = 0; tx < tcx; tx++) {
+        Viewport vp;
+        vp.offx = tx * tsx; vp.offy = ty * tsy;
+        vp.vpw = (W - vp.offx) < tsx ? (W - vp.offx) : tsx;
+        vp.vph = (H - vp.offy) < tsy ? (H - vp.offy) : tsy;
+        if (vp.vpw <= 0 || vp.vph <= 0) continue;
+        vp.xs = (float)W / (float)vp.vpw;
+        vp.ys = (float)H / (float)vp.vph;
+        vp.xo = (float)(W - vp.vpw - 2 * vp.offx) / (float)vp.vpw;
+        vp.yo = (float)(H - vp.vph - 2 * vp.offy) / (float)vp.vph;
+
+        NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4, stream));
+
+        SetupParams sp;
+        sp.pos = pos; sp.tri = tri; sp.ranges = ranges;
+        sp.instance = instance_mode ? 1 : 0; sp.N = N; sp.V = V; sp.T = T; sp.maxTri = max_tri; sp.slots = L.slots;
+        sp.vp = vp; sp.rec = rec; sp.bbox = bbox; sp.poolCount = pool;
+        {
+            ProfileScope ps("raster_setup", stream);
+            hipLaunchKernelGGL(k_setup, dim3((max_tri + 255) / 256, N, 1), dim3(256), 0, stream, sp);
+        }
+        NVDR_LAUNCH_CHECK();
+
+        FineParams fp;
+        fp.rec = rec; fp.bbox = bbox; fp.poolCount = pool; fp.ranges = ranges; fp.pos = pos; fp.tri = tri;
+        fp.instance = sp.instance; fp.N = N; fp.V = V; fp.T = T; fp.maxTri = max_tri; fp.slots = L.slots;
+        fp.W = W; fp.H = H; fp.Wp = Wp; fp.Hp = Hp; fp.vp = vp;
+        const int vpwPad = (vp.vpw + 7) & ~7, vphPad = (vp.vph + 7) & ~7;
+        fp.binsX = (vpwPad / 8 + kBinTiles - 1) / kBinTiles;
+        fp.binsY = (vphPad / 8 + kBinTiles - 1) / kBinTiles;
+        fp.totalBins = N * fp.binsX * fp.binsY;
+        fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
+        fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
+        fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
+        const int grid = ((fp.totalBins + 7) / 8) * 8;
+        {
+            ProfileScope ps("raster_fine", stream);
+            if (peel_depth && depth_out)       hipLaunchKernelGGL((k_fine<true, true>),   dim3(grid), dim3(kFineThreads), 0, stream, fp);
+            else if (peel_depth)               hipLaunchKernelGGL((k_fine<true, false>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);
+            else if (depth_out)                hipLaunchKernelGGL((k_fine<false, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);
+            else                               hipLaunchKernelGGL((k_fine<false, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);
+        }
+        NVDR_LAUNCH_CHECK();
+    }
+    return NVDR_OK;
+}
+
+extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,
+                                   const float* dy, const float* ddb,
+                                   int instance_mode, int N, int V, int T, int H, int W,
+                                   float* grad_pos, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_REQUIRE(pos && tri && out && dy && grad_pos, "rasterize_grad: null pointer");
+    NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "resolution must be [>0, >0, >0]");
+    NVDR_REQUIRE(V > 0 && T > 0, "rasterize_grad: empty input");
+    NVDR_REQUIRE(!((uintptr_t)pos & 15), "pos input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)dy & 15), "dy input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)ddb & 15), "ddb input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)out & 15), "out tensor not aligned to float4");
+    GradParams p;
+    p.pos = pos; p.tri = tri; p.out = out; p.dy = dy; p.ddb = ddb; p.grad = grad_pos;
+    p.instance = instance_mode ? 1 : 0; p.N = N; p.V = V; p.T = T; p.W = W; p.H = H;
+    p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
+    p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
+    dim3 grid((W + 31) / 32, (H + 7) / 8, N);
+    {
+        ProfileScope ps(ddb ? "raster_grad_db" : "raster_grad", stream);
+        if (ddb) hipLaunchKernelGGL(k_raster_grad<true>,  grid, dim3(256), 0, stream, p);
+        else     hipLaunchKernelGGL(k_raster_grad<false>, grid, dim3(256), 0, stream, p);
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}

@@ -1,0 +1,197 @@
+"""GPU parity: HIP rasterize / interpolate (through the C ABI) vs the CPU oracle.
+
+Bars (north_star): triangle-id channel bit-exact; barycentrics / z/w / attribute values and
+gradients within 1e-5 abs (position gradients, whose magnitude is O(100), within
+1e-5 * max(1, |g|_inf) -- an f32 atomic sum cannot do better than its own ulp)."""
+import numpy as np
+import pytest
+import torch
+
+from nvdiffrast_amd.utils import m10k_batch, stress_triangles
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+
+
+def _t(a, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _raster_pair(dr, oracle, pos, tri, res, ranges=None):
+    ctx = dr.RasterizeCudaContext()
+    r, rdb = dr.rasterize(ctx, _t(pos), _t(tri), res, ranges=None if ranges is None else torch.from_numpy(ranges))
+    ro, rdbo = oracle.rasterize(pos, tri, res, ranges=ranges)
+    return r.cpu().numpy(), rdb.cpu().numpy(), ro, rdbo
+
+
+def _check_raster(r, rdb, ro, rdbo, db_tol=None):
+    assert r.shape == ro.shape
+    mism = int((r[..., 3] != ro[..., 3]).sum())
+    assert mism == 0, f"{mism} triangle-id mismatches"
+    assert np.abs(r[..., :3] - ro[..., :3]).max() <= ATOL
+    if db_tol is None:
+        db_tol = ATOL * max(1.0, float(np.abs(rdbo).max()))
+    assert np.abs(rdb - rdbo).max() <= db_tol
+
+
+def test_triangle_sample(dr, oracle):
+    """BASELINE config 1: samples/torch/triangle.py inputs; oracle is pinned to tri.png."""
+    pos = np.array([[[-0.8, -0.8, 0, 1], [0.8, -0.8, 0, 1], [-0.8, 0.8, 0, 1]]], np.float32)
+    col = np.array([[[1, 0, 0], [0, 1, 0], [0, 0, 1]]], np.float32)
+    tri = np.array([[0, 1, 2]], np.int32)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, tri, (256, 256))
+    _check_raster(r, rdb, ro, rdbo)
+    out, _ = dr.interpolate(_t(col), _t(r), _t(tri))
+    img = np.clip(np.rint(out.cpu().numpy()[0, ::-1] * 255), 0, 255).astype(np.uint8)
+    from PIL import Image
+    import os
+    g = np.array(Image.open(os.path.join(os.path.dirname(__file__), "golden", "tri.png")))
+    assert (img != g).sum() == 0
+
+
+@pytest.mark.parametrize("res", [(512, 512), (250, 333), (64, 72), (8, 8), (5, 3)])
+def test_lattice_mesh_ids_exact(dr, oracle, res):
+    b = m10k_batch(3, seed=11)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, b["pos"], b["tri"], res)
+    _check_raster(r, rdb, ro, rdbo)
+
+
+def test_stress_overdraw(dr, oracle):
+    s = stress_triangles(2, T=4000, res=256, seed=3)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, s["pos"], s["tri"], (256, 256))
+    _check_raster(r, rdb, ro, rdbo)
+
+
+def test_clipping_and_huge_triangles(dr, oracle):
+    """Triangles crossing every frustum plane incl. w<=0 vertices (clipper path, pool slots)."""
+    rng = np.random.default_rng(5)
+    T = 600
+    pos = rng.normal(size=(2, 3 * T, 4)).astype(np.float32) * np.array([2.0, 2.0, 1.5, 1.0], np.float32)
+    pos[..., 3] = rng.uniform(-0.5, 2.0, size=pos.shape[:2])
+    tri = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, tri, (128, 200))
+    mism = int((r[..., 3] != ro[..., 3]).sum())
+    assert mism == 0
+    # barycentrics of clipped triangles can be ill-conditioned near w=0; compare where well-posed
+    ok = np.isfinite(ro).all(-1) & np.isfinite(r).all(-1)
+    assert np.abs(r[ok][:, :3] - ro[ok][:, :3]).max() <= 1e-4
+
+
+def test_depth_ties_and_duplicates(dr, oracle):
+    """Coplanar duplicates: the highest triangle index must win (FineRaster.inl:152-172)."""
+    b = m10k_batch(1, seed=2, nx=20, ny=10)
+    tri = np.concatenate([b["tri"], b["tri"][::-1], b["tri"]], 0)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, b["pos"], tri, (160, 160))
+    _check_raster(r, rdb, ro, rdbo)
+    assert (r[..., 3][r[..., 3] > 0] > 2 * b["tri"].shape[0]).all()
+
+
+def test_range_mode(dr, oracle):
+    b = m10k_batch(1, seed=4, nx=30, ny=20)
+    pos = b["pos"][0]
+    T = b["tri"].shape[0]
+    ranges = np.array([[0, T], [100, 500], [T - 7, 7], [3, 0]], np.int32)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, b["tri"], (96, 128), ranges=ranges)
+    _check_raster(r, rdb, ro, rdbo)
+
+
+def test_large_list_multi_round(dr, oracle):
+    """More triangles in one 64x64 bin than the LDS list holds -> several filter/raster rounds."""
+    rng = np.random.default_rng(9)
+    T = 5000
+    c = rng.uniform(-0.1, 0.1, size=(T, 1, 2))
+    xy = c + rng.uniform(-0.05, 0.05, size=(T, 3, 2))
+    z = rng.uniform(-0.9, 0.9, size=(T, 3, 1))
+    pos = np.concatenate([xy, z, np.ones_like(z)], -1).reshape(1, -1, 4).astype(np.float32)
+    tri = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, tri, (256, 256))
+    _check_raster(r, rdb, ro, rdbo)
+
+
+def test_depth_peeling(dr, oracle):
+    s = stress_triangles(2, T=1500, res=128, seed=8)
+    pos, tri = _t(s["pos"]), _t(s["tri"])
+    ctx = dr.RasterizeCudaContext()
+    peel = None
+    with dr.DepthPeeler(ctx, pos, tri, (128, 128)) as peeler:
+        for layer in range(4):
+            r, rdb = peeler.rasterize_next_layer()
+            ro, rdbo, depth = oracle.rasterize(s["pos"], s["tri"], (128, 128), peel_depth=peel, return_depth=True)
+            peel = depth
+            _check_raster(r.cpu().numpy(), rdb.cpu().numpy(), ro, rdbo)
+    assert isinstance(dr.rasterize(ctx, pos, tri, (128, 128)), tuple)
+
+
+@pytest.mark.parametrize("A", [1, 2, 3, 4, 7])
+def test_interpolate_forward(dr, oracle, A):
+    b = m10k_batch(2, seed=6, attrs=A)
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], (128, 160))
+    for attr in (b["attr"], np.repeat(b["attr"], 2, 0) * np.array([1.0, 0.5], np.float32).reshape(2, 1, 1)):
+        out, da = dr.interpolate(_t(attr), _t(ro), _t(b["tri"]))
+        oo, _ = oracle.interpolate(attr, ro, b["tri"])
+        assert da.shape == (2, 128, 160, 0)
+        assert np.abs(out.cpu().numpy() - oo).max() <= ATOL
+        out, da = dr.interpolate(_t(attr), _t(ro), _t(b["tri"]), rast_db=_t(rdbo), diff_attrs="all")
+        oo, dao = oracle.interpolate(attr, ro, b["tri"], rast_db=rdbo, diff_attrs="all")
+        assert np.abs(out.cpu().numpy() - oo).max() <= ATOL
+        assert np.abs(da.cpu().numpy() - dao).max() <= ATOL * max(1.0, np.abs(dao).max())
+    lst = [A - 1, 0, -1]
+    out, da = dr.interpolate(_t(b["attr"]), _t(ro), _t(b["tri"]), rast_db=_t(rdbo), diff_attrs=lst)
+    oo, dao = oracle.interpolate(b["attr"], ro, b["tri"], rast_db=rdbo, diff_attrs=lst)
+    assert np.abs(da.cpu().numpy() - dao).max() <= ATOL * max(1.0, np.abs(dao).max())
+
+
+def _grad_tol(ref):
+    return ATOL * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("grad_db", [True, False])
+def test_raster_interp_backward(dr, oracle, grad_db):
+    """The benchmark's op graph at a size the oracle finishes quickly."""
+    N, res = 3, (256, 256)
+    b = m10k_batch(N, seed=21)
+    rng = np.random.default_rng(0)
+    G = rng.normal(size=(N, res[0], res[1], 4)).astype(np.float32)
+    Gdb = rng.normal(size=(N, res[0], res[1], 4)).astype(np.float32) * 0.01
+    pos = _t(b["pos"]).requires_grad_(True)
+    attr = _t(b["attr"]).requires_grad_(True)
+    tri = _t(b["tri"])
+    ctx = dr.RasterizeCudaContext()
+    rast, rast_db = dr.rasterize(ctx, pos, tri, res, grad_db=grad_db)
+    out, _ = dr.interpolate(attr, rast, tri)
+    loss = (out * _t(G)).sum() + (rast_db * _t(Gdb)).sum()
+    loss.backward()
+
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    g_attr, g_rast, _ = oracle.interpolate_grad(b["attr"], ro, b["tri"], G)
+    g_pos = oracle.rasterize_grad(b["pos"], b["tri"], ro, g_rast, ddb=Gdb if grad_db else None)
+    assert np.abs(attr.grad.cpu().numpy() - g_attr).max() <= _grad_tol(g_attr)
+    assert np.abs(pos.grad.cpu().numpy() - g_pos).max() <= _grad_tol(g_pos)
+
+
+def test_interpolate_backward_da(dr, oracle):
+    N, res = 2, (96, 128)
+    b = m10k_batch(N, seed=22, attrs=3)
+    rng = np.random.default_rng(1)
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    for diff in ("all", [2, 0]):
+        D = 3 if diff == "all" else 2
+        G = rng.normal(size=(N, res[0], res[1], 3)).astype(np.float32)
+        Gda = rng.normal(size=(N, res[0], res[1], 2 * D)).astype(np.float32)
+        attr = _t(b["attr"]).requires_grad_(True)
+        rast = _t(ro).requires_grad_(True)
+        rast_db = _t(rdbo).requires_grad_(True)
+        out, da = dr.interpolate(attr, rast, _t(b["tri"]), rast_db=rast_db, diff_attrs=diff)
+        ((out * _t(G)).sum() + (da * _t(Gda)).sum()).backward()
+        g_attr, g_rast, g_rdb = oracle.interpolate_grad(b["attr"], ro, b["tri"], G, rast_db=rdbo, dda=Gda, diff_attrs=diff)
+        assert np.abs(attr.grad.cpu().numpy() - g_attr).max() <= _grad_tol(g_attr)
+        assert np.abs(rast.grad.cpu().numpy() - g_rast).max() <= _grad_tol(g_rast)
+        assert np.abs(rast_db.grad.cpu().numpy() - g_rdb).max() <= _grad_tol(g_rdb)
+
+
+def test_viewport_tiling_beyond_2048(dr, oracle):
+    """Images larger than one 2048^2 viewport are rasterised in viewport tiles (torch_rasterize.cpp:99-124)."""
+    b = m10k_batch(1, seed=30, nx=12, ny=8)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, b["pos"], b["tri"], (2100, 2500))
+    _check_raster(r, rdb, ro, rdbo)
