@@ -62,8 +62,9 @@ def lattice_mesh(rng, nx=100, ny=50, extent=0.9, jitter=0.4):
     return verts, tri, uv
 
 
-def m10k_batch(N, seed=20240, nx=100, ny=50, attrs=4):
-    """Benchmark geometry: returns dict(pos [N,V,4], tri [T,3], attr [1,V,attrs], uv [1,V,2])."""
+def m10k_batch(N, seed=20240, nx=100, ny=50, attrs=4, pose_seed=None):
+    """Benchmark geometry: returns dict(pos [N,V,4], tri [T,3], attr [1,V,attrs], uv [1,V,2]).
+    The mesh depends on ``seed`` only; item n's pose on ``pose_seed + n`` (default: seed + n)."""
     rng = np.random.default_rng(seed)
     verts, tri, uv = lattice_mesh(rng, nx, ny)
     attr = rng.uniform(0.0, 1.0, size=(1, verts.shape[0], attrs)).astype(np.float32)
@@ -71,7 +72,7 @@ def m10k_batch(N, seed=20240, nx=100, ny=50, attrs=4):
     proj = perspective(x=0.4, n=1.0, f=50.0).astype(np.float64) @ translation(0, 0, -3.5).astype(np.float64)
     pos = np.empty((N, verts.shape[0], 4), np.float32)
     for n in range(N):
-        pose = random_pose(np.random.default_rng(seed + n), 0.25)
+        pose = random_pose(np.random.default_rng((seed if pose_seed is None else pose_seed) + n), 0.25)
         pos[n] = (vh @ (proj @ pose).T).astype(np.float32)
     return dict(pos=pos, tri=tri, attr=attr, uv=uv[None])
 
