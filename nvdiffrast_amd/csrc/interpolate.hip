@@ -20,7 +20,7 @@ struct InterpParams {
     float* out; float* outDA; float* gradAttr; float* gradRaster; float* gradRasterDB;
     int numTriangles, numVertices, numAttr, numDiffAttr;
     int width, height, depth;
-    int attrBC, instance_mode, diff_attrs_all;
+    int attrBC, instance_mode, diff_attrs_all, dbg;
     int diffAttrs[kMaxDiffAttrs];
 };
 
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void k_interp_grad(const InterpParams p)
                 float dv = d.x * db.z + d.y * db.w;
                 c0 += du; c1 += dv; c2 += -du - dv;
             }
-            float s0 = it.sum(c0), s1 = it.sum(c1), s2 = it.sum(c2);
-            if (it.writer()) { atomic_add_f32(g0 + i, s0); atomic_add_f32(g1 + i, s1); atomic_add_f32(g2 + i, s2); }
+            float s0 = (p.dbg & 2) ? c0 : it.sum(c0), s1 = (p.dbg & 2) ? c1 : it.sum(c1), s2 = (p.dbg & 2) ? c2 : it.sum(c2);
+            if (it.writer() && !(p.dbg & 1)) { atomic_add_f32(g0 + i, s0); atomic_add_f32(g1 + i, s1); atomic_add_f32(g2 + i, s2); }
         }
         if (ENABLE_DA && !foldDA) {
             for (int i = 0; i < p.numDiffAttr; i++) {
@@ -213,6 +213,7 @@ static int fill_params(InterpParams& p, const float* attr, const float* rast, co
     p.attrBC = (attr_instance && attr_n == 1 && N > 1) ? 1 : 0;
     if (attr_instance && attr_n == 1) p.attrBC = 1;
     p.numDiffAttr = 0;
+    p.dbg = debug_flags();
     if (enable_da) {
         if (diff_all) { p.numDiffAttr = A; p.diff_attrs_all = 1; }
         else {

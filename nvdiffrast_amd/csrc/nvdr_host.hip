@@ -1,6 +1,7 @@
 // nvdr_host.hip -- error string, ABI version and the optional kernel timers.
 #include "nvdr_host.hpp"
 
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -25,6 +26,15 @@ static std::vector<hipEvent_t> g_pool;
 static thread_local Timed g_cur;
 
 bool profile_on() { return g_prof; }
+
+static unsigned long long* g_dbgbuf = nullptr;
+unsigned long long* debug_buffer() { return g_dbgbuf; }
+
+int debug_flags() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NVDR_DEBUG"); v = e ? atoi(e) : 0; }
+    return v;
+}
 
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -51,6 +61,7 @@ const char* nvdr_last_error(void) { return nvdr::g_err; }
 int nvdr_abi_version(void) { return 1; }
 
 void nvdr_profile_enable(int on) { nvdr::g_prof = on != 0; }
+void nvdr_debug_buffer(void* p) { nvdr::g_dbgbuf = (unsigned long long*)p; }
 
 void nvdr_profile_reset(void) {
     std::lock_guard<std::mutex> l(nvdr::g_mu);

@@ -23,6 +23,11 @@ struct ProfileScope {
     ~ProfileScope() { if (on) profile_end(s); }
 };
 
+// Experiment knob (NVDR_DEBUG env, read once): bit0 = skip gradient atomics, bit1 = skip group reductions.
+int debug_flags();
+// Optional device buffer for in-kernel timestamps (development only; nvdr_debug_buffer()).
+unsigned long long* debug_buffer();
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

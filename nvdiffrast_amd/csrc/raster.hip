@@ -41,7 +41,7 @@ constexpr int      kSubPerTri = 7;                       // clipper output: <= 9
 constexpr int kBinTiles   = 8;                           // bin = 8x8 tiles = 64x64 px
 constexpr int kFineWaves  = 8;
 constexpr int kFineThreads = kFineWaves * 64;
-constexpr int kListCap    = 512;                         // LDS triangle list capacity
+constexpr int kListCap    = 448;                         // LDS triangle list capacity
 
 struct Viewport {
     int   vpw, vph;            // viewport size in pixels (unpadded)
@@ -51,9 +51,10 @@ struct Viewport {
 
 struct SetupParams {
     const float* pos; const int* tri; const int* ranges;
-    int instance, N, V, T, maxTri, slots;
+    int instance, N, V, T, maxTri, poolBase, slots;
     Viewport vp;
     uint4* rec; uint32_t* bbox; int* poolCount;
+    int* binCount; int binsX, binsY;       // per (image, 64x64 bin) triangle counts, filled here
 };
 
 // ---------------------------------------------------------------------------------
@@ -188,7 +189,7 @@ __device__ bool snap_cull_setup(const Viewport& vp, const float (*v)[4], SubTri&
 // Record layout (4 x uint4):
 //   q0 = {A0, B0, C0, A1}   q1 = {B1, C1, A2, B2}   q2 = {C2, zx, zy, zb}   q3 = {id, aabb, 0, 0}
 // with E_e(X,Y) = C_e + X*A_e + Y*B_e >= 0  <=>  pixel (X,Y) is inside edge e.
-__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id)
+__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id, int* s_hist)
 {
     const Viewport& vp = p.vp;
     int bx = (vp.vpw - 1) << (kSpLog2 - 1);
@@ -200,6 +201,9 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     size_t so = (size_t)n * p.slots + slot;
     if (x0 > x1 || y0 > y1) { p.bbox[so] = kEmptyBox; return; }
     uint32_t box = (uint32_t)(x0 >> 3) | ((uint32_t)(y0 >> 3) << 8) | ((uint32_t)(x1 >> 3) << 16) | ((uint32_t)(y1 >> 3) << 24);
+    for (int by_ = y0 >> 6; by_ <= (y1 >> 6); by_++)
+        for (int bx_ = x0 >> 6; bx_ <= (x1 >> 6); bx_++)
+            atomicAdd(&s_hist[by_ * p.binsX + bx_], 1);
 
     uint32_t A[3], B[3], C[3];
 #pragma unroll
@@ -251,7 +255,7 @@ __device__ int clip_poly_plane(float* out, const float* in, int n_in, float f0, 
 
 // Slow path, TriangleSetup.inl:355-434 + Util.inl:134-160.  Kept out of line so the common
 // path stays small.
-__device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id)
+__device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist)
 {
 #pragma clang fp contract(off)
     float d1[4], d2[4], bary[18], tmp[18];
@@ -284,19 +288,17 @@ __device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot
     }
 
     if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return; }
-    emit_record(p, n, slot0, st[0], id);
+    emit_record(p, n, slot0, st[0], id, s_hist);
     if (ns > 1) {
-        int base = atomicAdd(&p.poolCount[n], ns - 1);       // cannot exceed slots - maxTri by construction
+        int base = atomicAdd(&p.poolCount[n], ns - 1);       // cannot exceed slots - poolBase by construction
         for (int k = 1; k < ns; k++)
-            emit_record(p, n, p.maxTri + base + k - 1, st[k], id);
+            emit_record(p, n, p.poolBase + base + k - 1, st[k], id, s_hist);
     }
 }
 
-__global__ __launch_bounds__(256) void k_setup(const SetupParams p)
+__device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, int* s_hist)
 {
 #pragma clang fp contract(off)
-    int n = blockIdx.y;
-    int i = blockIdx.x * 256 + threadIdx.x;
     int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
     if (i >= cnt) return;
     size_t so = (size_t)n * p.slots + i;
@@ -331,10 +333,58 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
 
     if (inside) {                                                                    // :329-352
         SubTri st;
-        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1);
+        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist);
         else p.bbox[so] = kEmptyBox;
     } else {
-        setup_clipped(p, n, i, v, t + 1);
+        setup_clipped(p, n, i, v, t + 1, s_hist);
+    }
+}
+
+constexpr int kMaxBins = 1024;          // (2048 / 64)^2 bins per viewport tile
+
+__global__ __launch_bounds__(256) void k_setup(const SetupParams p)
+{
+    __shared__ int s_hist[kMaxBins];
+    const int nb = p.binsX * p.binsY;
+    for (int b = threadIdx.x; b < nb; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    const int n = blockIdx.y;
+    setup_one(p, n, blockIdx.x * 256 + threadIdx.x, s_hist);
+    __syncthreads();
+    // One global atomic per non-empty bin per block (instead of one per triangle).
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        int c = s_hist[b];
+        if (c) atomicAdd(&p.binCount[(size_t)n * nb + b], c);
+    }
+}
+
+// Heavy-first work order.  Work items (image, bin) are partitioned into 8 contiguous chunks,
+// one per XCD (block b of k_fine runs on XCD b % 8, so an image's bins share one L2); inside
+// its chunk each XCD visits the bins with the most triangles first, which keeps the long
+// bins off the tail of the launch.  Counting sort by log2 bucket, one block per chunk.
+__global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount, int* __restrict__ order, int totalBins)
+{
+    __shared__ int s_bucket[32];
+    const int perXcd = (totalBins + 7) >> 3;
+    const int lo = blockIdx.x * perXcd, hi = min(lo + perXcd, totalBins);
+    if (threadIdx.x < 32) s_bucket[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        int c = binCount[i];
+        int bk = c > 0 ? 32 - __clz(c) : 0;              // 0, 1, 2-3, 4-7, ...
+        atomicAdd(&s_bucket[31 - bk], 1);                 // descending
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < 32; k++) { int c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+        int c = binCount[i];
+        int bk = c > 0 ? 32 - __clz(c) : 0;
+        int pos = atomicAdd(&s_bucket[31 - bk], 1);
+        order[lo + pos] = i;
     }
 }
 
@@ -344,162 +394,280 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
 
 struct FineParams {
     const uint4* rec; const uint32_t* bbox; const int* poolCount; const int* ranges;
+    const int* binCount; const int* order;
     const float* pos; const int* tri;
-    int instance, N, V, T, maxTri, slots;
+    int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
     Viewport vp;
     int binsX, binsY, totalBins;   // bins per viewport tile, N*binsX*binsY
     const uint32_t* peel; uint32_t* depth;
     float* out; float* out_db;
     float xs, xo, ys, yo;          // pixel -> clip transform of the whole image (torch_rasterize.cpp:146-149)
+    int dbg;
+    unsigned long long* dbgbuf;    // development: per-workgroup phase timestamps
 };
 
-// One candidate triangle against one 8x8 tile, all 64 pixels at once.
+constexpr int kQueueSize = 128;    // per-wave (triangle, tile) pair ring
+
+struct FineShared {
+    uint32_t slot[kListCap];                               // bin triangle list: record slot of each entry
+    uint32_t box[kListCap];                                // packed tile AABBs of the list entries
+    unsigned long long key[kBinTiles][kBinTiles][64];      // per-pixel visibility keys of the bin [tileY][tileX][pixel]
+    uint32_t queue[kFineWaves][kQueueSize];                // pair ring: entry | tileX << 16 | tileY << 20
+    int count;
+};
+
+// Rasterise up to 64 (triangle, tile) pairs, one pair per lane.
+//  1. coverage: each lane walks its triangle's three edge functions over the 8x8 pixel
+//     centres of its tile (integer adds only) and packs the signs into a 64-bit mask;
+//  2. fragments: each lane pops the set bits of its mask, evaluates the U32 depth plane
+//     and merges depth<<32|~id into the tile's key array with an LDS 64-bit atomic min.
+// Bit b of the mask is pixel (x, y) = (7 - (b & 7), 7 - (b >> 3)) of the tile.
 template <bool PEEL>
-__device__ __forceinline__ void raster_hit(const uint4* __restrict__ r, int X, int Y, uint32_t peelz, uint64_t& key)
+__device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
+                                             int wave, int lane, int n, int head, int npairs, int btx0, int bty0)
 {
-    uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-    // Edge functions in wrapping 32-bit arithmetic; operands fit 24 bits (|A|,|B| <= 2^20, X,Y < 2^11).
-    uint32_t e0 = q0.z + (uint32_t)__mul24((int)q0.x, X) + (uint32_t)__mul24((int)q0.y, Y);
-    uint32_t e1 = q1.y + (uint32_t)__mul24((int)q0.w, X) + (uint32_t)__mul24((int)q1.x, Y);
-    uint32_t e2 = q2.x + (uint32_t)__mul24((int)q1.z, X) + (uint32_t)__mul24((int)q1.w, Y);
-    bool covered = (int)(e0 | e1 | e2) >= 0;
-    uint32_t depth = q2.y * (uint32_t)X + q2.z * (uint32_t)Y + q2.w;            // FineRaster.inl:348
-    if (PEEL) covered = covered && (depth > peelz);                             // :349
-    uint64_t k = ((uint64_t)depth << 32) | (uint32_t)~q3.x;
-    if (covered && k < key) key = k;                                            // LEQUAL in order == min key
+    const bool act = lane < npairs;
+    const uint32_t q = sh.queue[wave][(head + lane) & (kQueueSize - 1)];
+    const int e = act ? (int)(q & 0xFFFFu) : 0;
+    const int tx = act ? (int)((q >> 16) & 15u) : 0;
+    const int tyl = act ? (int)(q >> 20) : 0;
+    const int X0 = (btx0 + tx) * 8, Y0 = (bty0 + tyl) * 8;
+
+    // Each lane gathers its triangle's 64-byte record from L2 (the image's records are L2 resident).
+    const uint4* r = grec + (size_t)(act ? sh.slot[e] : sh.slot[0]) * 4;
+    const uint4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+    int A0 = (int)q0.x, B0 = (int)q0.y;
+    int A1 = (int)q0.w, B1 = (int)q1.x;
+    int A2 = (int)q1.z, B2 = (int)q1.w;
+    // Edge values at the tile's first pixel; wrapping 32-bit arithmetic, 24-bit operands.
+    uint32_t e0 = q0.z + (uint32_t)__mul24(A0, X0) + (uint32_t)__mul24(B0, Y0);
+    uint32_t e1 = q1.y + (uint32_t)__mul24(A1, X0) + (uint32_t)__mul24(B1, Y0);
+    uint32_t e2 = q2.x + (uint32_t)__mul24(A2, X0) + (uint32_t)__mul24(B2, Y0);
+
+    uint32_t mhi = 0, mlo = 0;                   // rows 0..3 -> mhi, rows 4..7 -> mlo (sign bits = outside)
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        uint32_t r0 = e0, r1 = e1, r2 = e2, bits = (y < 4) ? mhi : mlo;
+#pragma unroll
+        for (int x = 0; x < 8; x++) {
+            bits = __builtin_amdgcn_alignbit(bits, r0 | r1 | r2, 31);     // (bits << 1) | sign
+            r0 += (uint32_t)A0; r1 += (uint32_t)A1; r2 += (uint32_t)A2;
+        }
+        if (y < 4) mhi = bits; else mlo = bits;
+        e0 += (uint32_t)B0; e1 += (uint32_t)B1; e2 += (uint32_t)B2;
+    }
+    uint64_t m = act ? ~(((uint64_t)mhi << 32) | mlo) : 0ull;
+    if (__ballot(m != 0) == 0) return;
+
+    if (p.dbg & 32) return;
+    const uint32_t zx = q2.y, zy = q2.z;
+    const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
+    const uint32_t d0 = q2.w + zx * (uint32_t)X0 + zy * (uint32_t)Y0;   // depth at the tile origin
+    const uint32_t idk = ~q3.x;
+    unsigned long long* keys = sh.key[tyl][tx];
+    // Start each lane at a different bit so that equal masks do not all hit one LDS address.
+    const int rot = lane & 63;
+    m = (m >> rot) | (m << ((64 - rot) & 63));
+    while (__ballot(m != 0)) {
+        if (m != 0) {
+            int b = (__builtin_ctzll(m) + rot) & 63;
+            m &= m - 1;
+            uint32_t x = 7u - (uint32_t)(b & 7), y = 7u - (uint32_t)(b >> 3);
+            // zx*x + zy*y with x,y < 8 via 24-bit multiplies (FineRaster.inl:348 depth, U32 wrap).
+            uint32_t depth = d0 + __umul24(zxl, x) + (__umul24(zxh, x) << 24) + __umul24(zyl, y) + (__umul24(zyh, y) << 24);
+            bool live = true;
+            if (PEEL) {
+                uint32_t pz = p.peel[((size_t)n * p.Hp + (Y0 + (int)y + p.vp.offy)) * p.Wp + (X0 + (int)x + p.vp.offx)];
+                live = depth > pz;                                               // FineRaster.inl:349
+            }
+            if (live) atomicMin(&keys[y * 8 + x], ((unsigned long long)depth << 32) | idk);
+        }
+    }
 }
 
 template <bool PEEL, bool WRITE_DEPTH>
-__global__ __launch_bounds__(kFineThreads) void k_fine(const FineParams p)
+__global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fine(const FineParams p)
 {
-    __shared__ uint4    s_rec[kListCap * 4];
-    __shared__ uint32_t s_box[kListCap];
-    __shared__ int      s_count;
+    __shared__ FineShared sh;
 
-    // XCD-aware work assignment: blocks b, b+8, b+16, ... run on one XCD (observed b % 8
-    // placement) and get consecutive work items, i.e. the bins of the same image, so an
-    // image's records/AABBs/vertices stay in one L2.  Placement only affects speed.
+    // Work assignment.  Blocks b, b+8, b+16, ... run on one XCD (observed b % 8 placement)
+    // and walk that XCD's chunk of the heavy-first order produced by k_order, so an image's
+    // records / AABBs / vertices stay in one L2 and long bins start early.  Placement and
+    // order only affect speed.
     const int perXcd = (p.totalBins + 7) >> 3;
-    const int work = (int)(blockIdx.x & 7) * perXcd + (int)(blockIdx.x >> 3);
-    if (work >= p.totalBins) return;
+    const int item = (int)(blockIdx.x & 7) * perXcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= perXcd || item >= p.totalBins) return;
+    const int work = p.order[item];
     const int binsPerImage = p.binsX * p.binsY;
     const int n   = work / binsPerImage;
     const int bin = work - n * binsPerImage;
     const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
     const int btx0 = binX * kBinTiles, bty0 = binY * kBinTiles;
+    const int binTris = p.binCount[work];       // triangles whose AABB touches this bin
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ty = bty0 + wave;                 // this wave's tile row
     const int lx = lane & 7, ly = lane >> 3;
-    const int Y = ty * 8 + ly;                  // viewport-local pixel row
-
     const int vpwPad = (p.vp.vpw + 7) & ~7, vphPad = (p.vp.vph + 7) & ~7;
 
-    const int direct = p.instance ? p.T : p.ranges[2 * n + 1];
-    const int pool   = min(p.poolCount[n], p.slots - p.maxTri);
-    const int total  = direct + pool;
-    const uint32_t* gbox = p.bbox + (size_t)n * p.slots;
-    const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
-
-    const uint64_t kInit = ((uint64_t)kDepthMax << 32) | 0xFFFFFFFFull;
-    uint64_t key[kBinTiles];
-    uint32_t peelz[kBinTiles];
+    unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
+    if (p.dbgbuf) tstamp[0] = wall_clock64();
+    const unsigned long long kInit = ((unsigned long long)kDepthMax << 32) | 0xFFFFFFFFull;
 #pragma unroll
-    for (int t = 0; t < kBinTiles; t++) {
-        key[t] = kInit;
-        peelz[t] = 0;
-        if (PEEL) {
-            int X = (btx0 + t) * 8 + lx;
-            if (X < vpwPad && Y < vphPad)
-                peelz[t] = p.peel[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)];
-        }
-    }
-
-    if (threadIdx.x == 0) s_count = 0;
+    for (int t = 0; t < kBinTiles; t++) sh.key[wave][t][lane] = kInit;
+    if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
     __syncthreads();
 
-    int scan = wave * 64;      // this wave's position in the image's slot index space
-    int skip = 0;              // hits of the current 64-slot group already listed
-    bool done = (scan >= total);
+    if (binTris > 0) {
+        const int direct = p.instance ? p.T : p.ranges[2 * n + 1];
+        const int pool   = min(p.poolCount[n], p.slots - p.poolBase);
+        // Index space scanned by the filter: [0, directPad) = direct slots (padded to 4),
+        // [directPad, directPad + pool) = pool slots.  Four consecutive slots per lane per step.
+        const int directPad = (direct + 3) & ~3;
+        const int total = directPad + pool;
+        const uint32_t* gbox = p.bbox + (size_t)n * p.slots;
+        const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
 
-    for (;;) {
-        // ---- filter: compact this bin's triangles into the LDS list ----------------
-        while (!done) {
-            int idx = scan + lane;
-            int slot = (idx < direct) ? idx : p.maxTri + (idx - direct);
-            uint32_t box = (idx < total) ? gbox[slot] : kEmptyBox;
-            int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
-            bool hit = (txlo <= btx0 + kBinTiles - 1) & (txhi >= btx0) & (tylo <= bty0 + kBinTiles - 1) & (tyhi >= bty0);
-            uint64_t m = __ballot(hit);
-            int nh = __popcll(m) - skip;
-            if (nh > 0) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_count, nh);
-                base = __builtin_amdgcn_readfirstlane(base);
-                int can = min(max(kListCap - base, 0), nh);
-                int rank = mask_rank(m) - skip;
-                if (hit && rank >= 0 && rank < can) {
-                    int dst = base + rank;
-                    const uint4* src = grec + (size_t)slot * 4;
-                    s_rec[dst * 4 + 0] = src[0];
-                    s_rec[dst * 4 + 1] = src[1];
-                    s_rec[dst * 4 + 2] = src[2];
-                    s_rec[dst * 4 + 3] = src[3];
-                    s_box[dst] = box;
+        constexpr int kStep = kFineThreads * 4;     // slots per workgroup step
+        int scan = wave * 256;                      // this wave's position in the scanned index space
+        int sub = 0, skip = 0;                      // resume point inside the current group of 4x64 slots
+        bool done = (scan >= total);
+        int found = 0;                              // list entries consumed by earlier rounds
+
+        auto load_boxes = [&](int pos) -> uint4 {
+            int idx = pos + lane * 4;
+            uint4 b = make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
+            if (idx < total) {
+                int slot = (idx < directPad) ? idx : p.poolBase + (idx - directPad);
+                b = *(const uint4*)(gbox + slot);
+                if (idx < directPad) {              // mask the padding beyond `direct`
+                    if (idx + 1 >= direct) b.y = kEmptyBox;
+                    if (idx + 2 >= direct) b.z = kEmptyBox;
+                    if (idx + 3 >= direct) b.w = kEmptyBox;
+                    if (idx >= direct) b.x = kEmptyBox;
+                } else {
+                    int rem = total - idx;
+                    if (rem < 2) b.y = kEmptyBox;
+                    if (rem < 3) b.z = kEmptyBox;
+                    if (rem < 4) b.w = kEmptyBox;
                 }
-                if (can < nh) { skip += can; break; }       // list full: resume here after the flush
             }
-            skip = 0;
-            scan += kFineThreads;
-            done = (scan >= total);
-        }
-        const int allDone = __syncthreads_and(done ? 1 : 0);
-        const int cnt = min(s_count, kListCap);
+            return b;
+        };
 
-        // ---- raster: 64 list entries at a time against this wave's 8 tiles ---------
-        if (ty * 8 < vphPad) {
-            for (int c = 0; c < cnt; c += 64) {
-                int j = c + lane;
-                uint32_t box = (j < cnt) ? s_box[j] : kEmptyBox;
-                int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
-                bool rowhit = (tylo <= ty) & (ty <= tyhi);
-                if (__ballot(rowhit) == 0) continue;
-#pragma unroll
-                for (int t = 0; t < kBinTiles; t++) {
-                    const int tx = btx0 + t;
-                    uint64_t m = __ballot(rowhit & (txlo <= tx) & (tx <= txhi));
-                    const int X = tx * 8 + lx;
-                    while (m) {
-                        int b = __builtin_ctzll(m);
-                        m &= m - 1;
-                        raster_hit<PEEL>(&s_rec[(c + b) * 4], X, Y, peelz[t], key[t]);
+        uint4 cur = done ? make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox) : load_boxes(scan);
+
+        for (;;) {
+            // ---- filter: compact this bin's triangles into the LDS list ----------------
+            while (!done) {
+                if (found + sh.count >= binTris) { done = true; break; }       // every triangle of the bin is listed
+                const int nextScan = scan + kStep;
+                uint4 nxt = make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
+                if (nextScan < total) nxt = load_boxes(nextScan);      // prefetch the next group while this one is filtered
+                bool full = false;
+                for (; sub < 4; sub++) {
+                    uint32_t box = sub == 0 ? cur.x : sub == 1 ? cur.y : sub == 2 ? cur.z : cur.w;
+                    int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
+                    bool hit = (txlo <= btx0 + kBinTiles - 1) & (txhi >= btx0) & (tylo <= bty0 + kBinTiles - 1) & (tyhi >= bty0);
+                    uint64_t m = __ballot(hit);
+                    int nh = __popcll(m) - skip;
+                    if (nh > 0) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&sh.count, nh);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        int can = min(max(kListCap - base, 0), nh);
+                        int rank = mask_rank(m) - skip;
+                        if (hit && rank >= 0 && rank < can) {
+                            int dst = base + rank;
+                            int idx = scan + lane * 4 + sub;
+                            int slot = (idx < directPad) ? idx : p.poolBase + (idx - directPad);
+                            sh.slot[dst] = (uint32_t)slot;
+                            sh.box[dst] = box;
+                        }
+                        if (can < nh) { skip += can; full = true; break; }      // list full: resume here after the flush
+                    }
+                    skip = 0;
+                }
+                if (full) break;
+                sub = 0;
+                scan = nextScan;
+                done = (scan >= total);
+                cur = nxt;
+            }
+            unsigned long long tf0 = p.dbgbuf ? wall_clock64() : 0;
+            __syncthreads();
+            const int cnt = min(sh.count, kListCap);
+            found += cnt;
+            // The bin is finished when every wave has scanned to the end or all its triangles are listed.
+            const int allDone = __syncthreads_and((done || found >= binTris) ? 1 : 0);
+            unsigned long long tf1 = p.dbgbuf ? wall_clock64() : 0;
+            tstamp[1] += 1; tstamp[4] += cnt;
+
+            // ---- raster: every wave takes list chunks, queues their (triangle, tile) pairs and
+            //      rasterises them 64 at a time into the shared key arrays (LDS atomics) -------------
+            if (!(p.dbg & 4)) {
+                int head = 0, qn = 0;
+                for (int c = wave * 64; c < cnt; c += kFineWaves * 64) {
+                    int j = c + lane;
+                    uint32_t box = (j < cnt) ? sh.box[j] : kEmptyBox;
+                    int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
+                    int x0 = max(txlo, btx0), x1 = min(txhi, btx0 + kBinTiles - 1);
+                    int y0 = max(tylo, bty0), y1 = min(tyhi, bty0 + kBinTiles - 1);
+                    int nx = max(x1 - x0 + 1, 0), ny = max(y1 - y0 + 1, 0);
+                    if (nx == 0) ny = 0;
+                    for (int ky = 0; ky < kBinTiles; ky++) {
+                        if (__ballot(ky < ny) == 0) break;
+                        for (int kx = 0; kx < kBinTiles; kx++) {
+                            const bool push = (kx < nx) & (ky < ny);
+                            uint64_t m = __ballot(push);
+                            if (m == 0) break;
+                            if (push) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
+                                (uint32_t)j | ((uint32_t)(x0 + kx - btx0) << 16) | ((uint32_t)(y0 + ky - bty0) << 20);
+                            qn += __popcll(m);
+                            if (qn >= 64) {
+                                __builtin_amdgcn_wave_barrier();
+                                raster_pairs<PEEL>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0);
+                                __builtin_amdgcn_wave_barrier();
+                                head = (head + 64) & (kQueueSize - 1);
+                                qn -= 64;
+                            }
+                        }
                     }
                 }
+                if (qn > 0) {
+                    __builtin_amdgcn_wave_barrier();
+                    raster_pairs<PEEL>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0);
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
+            if (p.dbgbuf) { unsigned long long tr = wall_clock64(); tstamp[2] += tf1 - tf0; tstamp[3] += tr - tf1; }
+            __syncthreads();
+            if (allDone) break;
+            if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
+            __syncthreads();
         }
-        if (allDone) break;
-        __syncthreads();
-        if (threadIdx.x == 0) s_count = 0;
-        __syncthreads();
     }
 
-    // ---- pixel shader (rasterize.cu:15-114) + stores ---------------------------------
+    if (p.dbgbuf) tstamp[5] = wall_clock64();
+    // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w -----------
+    const int ty = bty0 + wave;
+    const int Y = ty * 8 + ly;                  // viewport-local pixel row
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
-#pragma unroll
+#pragma unroll 1
     for (int t = 0; t < kBinTiles; t++) {
         const int X = (btx0 + t) * 8 + lx;
+        const unsigned long long key = sh.key[wave][t][lane];
         if (WRITE_DEPTH) {
             if (X < vpwPad && Y < vphPad)
-                p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key[t] >> 32);
+                p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
         }
         if (X >= p.vp.vpw || Y >= p.vp.vph) continue;
         const int px = X + p.vp.offx, py = Y + p.vp.offy;
         const size_t pidx = ((size_t)n * p.H + py) * p.W + px;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), odb = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int triIdx = (int)(~(uint32_t)key[t]) - 1;
-        bool write = true;
+        const int triIdx = (p.dbg & 8) ? -1 : (int)(~(uint32_t)key) - 1;
+        bool write = !(p.dbg & 16);
         if (triIdx >= 0 && triIdx < p.T) {
             int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
             if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) {
@@ -539,6 +707,10 @@ __global__ __launch_bounds__(kFineThreads) void k_fine(const FineParams p)
             ((float4*)p.out_db)[pidx] = odb;
         }
     }
+    if (p.dbgbuf && lane == 0) {
+        unsigned long long* d = p.dbgbuf + ((size_t)item * kFineWaves + wave) * 8;
+        d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3]; d[4] = tstamp[4]; d[5] = tstamp[5]; d[6] = wall_clock64(); d[7] = (unsigned long long)work;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -550,6 +722,7 @@ struct GradParams {
     float* grad;
     int instance, N, V, T, W, H;
     float xs, xo, ys, yo;
+    int dbg;
 };
 
 // Block = 4 waves, each wave an 8x8 pixel tile (keeps a triangle's pixels in one wave so the
@@ -669,8 +842,8 @@ __global__ __launch_bounds__(256) void k_raster_grad(const GradParams p)
         const int w0 = it.bcast(vi0), w1 = it.bcast(vi1), w2 = it.bcast(vi2);
         float s[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) s[k] = it.sum(g[k]);
-        if (it.writer()) {
+        for (int k = 0; k < 9; k++) s[k] = (p.dbg & 2) ? g[k] : it.sum(g[k]);
+        if (it.writer() && !(p.dbg & 1)) {
             float* q0 = p.grad + (size_t)w0 * 4; float* q1 = p.grad + (size_t)w1 * 4; float* q2 = p.grad + (size_t)w2 * 4;
             atomic_add_f32(q0 + 0, s[0]); atomic_add_f32(q0 + 1, s[1]); atomic_add_f32(q0 + 3, s[2]);
             atomic_add_f32(q1 + 0, s[3]); atomic_add_f32(q1 + 1, s[4]); atomic_add_f32(q1 + 3, s[5]);
@@ -683,16 +856,26 @@ __global__ __launch_bounds__(256) void k_raster_grad(const GradParams p)
 // Host side
 // ---------------------------------------------------------------------------------
 
-struct ScratchLayout { size_t rec, bbox, pool, total; int slots; };
+struct ScratchLayout { size_t rec, bbox, pool, binCount, order, total; int slots, poolBase, maxBins; };
 
-static ScratchLayout scratch_layout(int N, int max_tri)
+static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
 {
     ScratchLayout L;
-    L.slots = max_tri * kSubPerTri;
+    {   // bins of the largest viewport tile (torch_rasterize.cpp:99-102 tiling)
+        const int Hp = (H + 7) & ~7, Wp = (W + 7) & ~7;
+        const int tcx = (Wp + kMaxViewport - 1) / kMaxViewport, tcy = (Hp + kMaxViewport - 1) / kMaxViewport;
+        const int tsx = ((Wp + tcx - 1) / tcx + 7) & ~7, tsy = ((Hp + tcy - 1) / tcy + 7) & ~7;
+        L.maxBins = ((tsx + 63) / 64) * ((tsy + 63) / 64);
+    }
+    L.poolBase = (max_tri + 3) & ~3;                       // pool slots start 16-byte aligned in the AABB array
+    L.slots = L.poolBase + (((kSubPerTri - 1) * max_tri + 3) & ~3);
     L.rec   = 0;
     L.bbox  = align_up(L.rec + (size_t)N * L.slots * 64, 256);
     L.pool  = align_up(L.bbox + (size_t)N * L.slots * 4, 256);
-    L.total = align_up(L.pool + (size_t)N * 4, 256);
+    // pool counters and per-bin counts are adjacent: one memset clears both
+    L.binCount = L.pool + (size_t)N * 4;
+    L.order = align_up(L.binCount + (size_t)N * L.maxBins * 4, 256);
+    L.total = align_up(L.order + (size_t)N * L.maxBins * 4, 256);
     return L;
 }
 
@@ -702,9 +885,8 @@ using namespace nvdr;
 
 extern "C" size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W)
 {
-    (void)H; (void)W;
-    if (N <= 0 || max_tri <= 0) return 0;
-    return scratch_layout(N, max_tri).total;
+    if (N <= 0 || max_tri <= 0 || H <= 0 || W <= 0) return 0;
+    return scratch_layout(N, max_tri, H, W).total;
 }
 
 extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
@@ -723,13 +905,15 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
     NVDR_REQUIRE(!((uintptr_t)out_db & 15), "out_db output tensor not aligned to float4");
     NVDR_REQUIRE(!((uintptr_t)scratch & 255), "scratch must be 256-byte aligned");
     NVDR_REQUIRE((long long)max_tri * kSubPerTri < (1ll << 31) / 4, "subtriangle count overflow");
-    ScratchLayout L = scratch_layout(N, max_tri);
+    ScratchLayout L = scratch_layout(N, max_tri, H, W);
     if (scratch_bytes < L.total) { set_error("rasterize_fwd: scratch too small (%zu < %zu)", scratch_bytes, L.total); return NVDR_ERR_SCRATCH; }
 
     char* sb = (char*)scratch;
     uint4* rec = (uint4*)(sb + L.rec);
     uint32_t* bbox = (uint32_t*)(sb + L.bbox);
     int* pool = (int*)(sb + L.pool);
+    int* binCount = (int*)(sb + L.binCount);
+    int* order = (int*)(sb + L.order);
 
     const int Hp = (H + 7) & ~7, Wp = (W + 7) & ~7;
     // Viewport tiling for images beyond 2048 px (torch_rasterize.cpp:99-124).
@@ -748,30 +932,40 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         vp.xo = (float)(W - vp.vpw - 2 * vp.offx) / (float)vp.vpw;
         vp.yo = (float)(H - vp.vph - 2 * vp.offy) / (float)vp.vph;
 
-        NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4, stream));
 
         SetupParams sp;
         sp.pos = pos; sp.tri = tri; sp.ranges = ranges;
-        sp.instance = instance_mode ? 1 : 0; sp.N = N; sp.V = V; sp.T = T; sp.maxTri = max_tri; sp.slots = L.slots;
+        sp.instance = instance_mode ? 1 : 0; sp.N = N; sp.V = V; sp.T = T; sp.maxTri = max_tri; sp.poolBase = L.poolBase; sp.slots = L.slots;
         sp.vp = vp; sp.rec = rec; sp.bbox = bbox; sp.poolCount = pool;
+        const int vpwPad = (vp.vpw + 7) & ~7, vphPad = (vp.vph + 7) & ~7;
+        const int binsX = (vpwPad / 8 + kBinTiles - 1) / kBinTiles;
+        const int binsY = (vphPad / 8 + kBinTiles - 1) / kBinTiles;
+        const int totalBins = N * binsX * binsY;
+        sp.binCount = binCount; sp.binsX = binsX; sp.binsY = binsY;
+        NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4 + (size_t)totalBins * 4, stream));
         {
             ProfileScope ps("raster_setup", stream);
             hipLaunchKernelGGL(k_setup, dim3((max_tri + 255) / 256, N, 1), dim3(256), 0, stream, sp);
         }
         NVDR_LAUNCH_CHECK();
+        {
+            ProfileScope ps("raster_order", stream);
+            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, order, totalBins);
+        }
+        NVDR_LAUNCH_CHECK();
 
         FineParams fp;
         fp.rec = rec; fp.bbox = bbox; fp.poolCount = pool; fp.ranges = ranges; fp.pos = pos; fp.tri = tri;
-        fp.instance = sp.instance; fp.N = N; fp.V = V; fp.T = T; fp.maxTri = max_tri; fp.slots = L.slots;
+        fp.instance = sp.instance; fp.N = N; fp.V = V; fp.T = T; fp.maxTri = max_tri; fp.poolBase = L.poolBase; fp.slots = L.slots;
         fp.W = W; fp.H = H; fp.Wp = Wp; fp.Hp = Hp; fp.vp = vp;
-        const int vpwPad = (vp.vpw + 7) & ~7, vphPad = (vp.vph + 7) & ~7;
-        fp.binsX = (vpwPad / 8 + kBinTiles - 1) / kBinTiles;
-        fp.binsY = (vphPad / 8 + kBinTiles - 1) / kBinTiles;
-        fp.totalBins = N * fp.binsX * fp.binsY;
+        fp.binsX = binsX; fp.binsY = binsY; fp.totalBins = totalBins;
+        fp.binCount = binCount; fp.order = order;
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
-        const int grid = ((fp.totalBins + 7) / 8) * 8;
+        fp.dbg = debug_flags();
+        fp.dbgbuf = debug_buffer();
+        const int grid = ((totalBins + 7) / 8) * 8;
         {
             ProfileScope ps("raster_fine", stream);
             if (peel_depth && depth_out)       hipLaunchKernelGGL((k_fine<true, true>),   dim3(grid), dim3(kFineThreads), 0, stream, fp);
@@ -802,6 +996,7 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
     p.instance = instance_mode ? 1 : 0; p.N = N; p.V = V; p.T = T; p.W = W; p.H = H;
     p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
     p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
+    p.dbg = debug_flags();
     dim3 grid((W + 31) / 32, (H + 7) / 8, N);
     {
         ProfileScope ps(ddb ? "raster_grad_db" : "raster_grad", stream);

@@ -1,0 +1,45 @@
+"""Development tool: per-workgroup phase timing of k_fine on the benchmark scene (uses nvdr_debug_buffer)."""
+import ctypes, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nvdiffrast_amd.torch as dr
+from nvdiffrast_amd import _capi
+from nvdiffrast_amd.utils import m10k_batch
+
+N = 64
+lib = _capi.load()
+lib.nvdr_debug_buffer.argtypes = [ctypes.c_void_p]
+dev = torch.device("cuda", 0)
+b = m10k_batch(N)
+pos = torch.from_numpy(b["pos"]).to(dev); tri = torch.from_numpy(b["tri"]).to(dev)
+ctx = dr.RasterizeCudaContext()
+for _ in range(3):
+    dr.rasterize(ctx, pos, tri, (512, 512))
+torch.cuda.synchronize()
+nwg = N * 64
+buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+lib.nvdr_debug_buffer(buf.data_ptr())
+dr.rasterize(ctx, pos, tri, (512, 512))
+torch.cuda.synchronize()
+lib.nvdr_debug_buffer(None)
+d = buf.cpu().numpy().reshape(nwg, 8, 8).astype(np.float64)
+t0 = d[:, :, 0].min()
+start = (d[:, 0, 0] - t0) / 100.0          # wall_clock64 = 100 MHz -> us
+end = (d[:, :, 6].max(1) - t0) / 100.0
+dur = end - start
+rounds = d[:, 0, 1]; filt = d[:, :, 2].max(1) / 100.0; rast = d[:, :, 3].max(1) / 100.0; cnt = d[:, 0, 4]
+shade = (d[:, :, 6] - d[:, :, 5]).max(1) / 100.0
+print("kernel span us", end.max(), "first start", start.min(), "last start", start.max())
+print("WG duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % (dur.mean(), *np.percentile(dur, [50, 90, 99]), dur.max()))
+print("filter us (max wave): mean %.1f p90 %.1f max %.1f" % (filt.mean(), np.percentile(filt, 90), filt.max()))
+print("raster us (max wave): mean %.1f p90 %.1f max %.1f" % (rast.mean(), np.percentile(rast, 90), rast.max()))
+print("shade+store us: mean %.1f p90 %.1f max %.1f" % (shade.mean(), np.percentile(shade, 90), shade.max()))
+print("rounds: mean %.2f max %d; list total mean %.0f max %d" % (rounds.mean(), rounds.max(), cnt.mean(), cnt.max()))
+idx = np.argsort(-dur)[:8]
+for i in idx:
+    print("WG", i, "img", i // 64, "bin", i % 64, "start %.1f dur %.1f filt %.1f rast %.1f shade %.1f rounds %d cnt %d" % (start[i], dur[i], filt[i], rast[i], shade[i], rounds[i], cnt[i]))
+# concurrency: how many WGs alive over time
+ts = np.linspace(0, end.max(), 20)
+print("alive WGs over time:", [(int(((start <= t) & (end > t)).sum())) for t in ts])
+emp = cnt == 0
+print("empty WGs: %d, their duration mean %.1f" % (emp.sum(), dur[emp].mean()))
