@@ -4,9 +4,10 @@
 //  k_interp_fwd   pure streaming: pixels are taken in linear order (one lane = one pixel,
 //                 a wave = 64 consecutive pixels = 1 KiB of rast per load instruction);
 //                 the three vertex attribute rows are gathered from L2.
-//  k_interp_grad  one wave per 8x8 pixel tile so that the pixels of one triangle meet in
-//                 one wave; attribute gradients are reduced per triangle with DPP and
-//                 issued as one hardware f32 atomic per (triangle, vertex, attribute).
+//  k_interp_grad  one workgroup per 64x32 pixel block streaming whole rows; attribute gradients
+//                 are summed over triangle runs in the wave, accumulated per vertex in an LDS
+//                 fixed-point hash table (ds_add_u64) and flushed as one hardware f32 atomic per
+//                 (vertex, attribute) per block.
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
 
@@ -96,100 +97,173 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 
 // ---- backward (interpolate.cu:131-274) -------------------------------------------------
 
-template <int A_CT, bool ENABLE_DA>
-__global__ __launch_bounds__(256) void k_interp_grad(const InterpParams p)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
-    const int py = blockIdx.y * 8 + (lane >> 3);
-    const int pz = blockIdx.z;
-    const int A = A_CT > 0 ? A_CT : p.numAttr;
-    const bool inImage = (px < p.width) && (py < p.height);
-    const size_t pidx = inImage ? ((size_t)pz * p.height + py) * p.width + px : 0;
+// Workgroup = 64 x 32 pixel block of one image, 8 waves, each wave owning four 64-pixel rows
+// (1 KiB coalesced accesses, four rows in flight).  Two phases around one barrier:
+//   A  per pixel: gradients w.r.t. the barycentrics (and their pixel differentials) are written
+//      out; the largest attribute-gradient contribution of the block is published (it fixes the
+//      fixed-point scale of the LDS accumulator, nvdr_device.hpp);
+//   B  the contributions b_k * dy_i are summed over runs of equal triangle id inside the wave
+//      (RunScan), the run totals go to the workgroup's LDS vertex table with ds_add_u64, and
+//      every touched (vertex, attribute) reaches memory as ONE global atomic per block.
+// The reference issues 3*A atomics per pixel behind a __match_any_sync coalescer
+// (interpolate.cu:198-210, common.h:205-216).  Table size comes from the host (dynamic LDS).
+constexpr int kIpBlockW = 64;
+constexpr int kIpBlockH = 32;
+constexpr int kIpThreads = 512;
+constexpr int kIpRowsPerWave = 4;
 
-    bool active = false;
-    int triIdx = -1, vi0 = 0, vi1 = 0, vi2 = 0;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inImage) {
-        r = ((const float4*)p.rast)[pidx];
-        triIdx = float_to_triidx(r.w) - 1;
+struct IpPixel { int tri, vi0, vi1, vi2; float b0, b1; };
+
+template <int A_CT, bool ENABLE_DA>
+__global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p, int slots, int gx, int gy)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    constexpr bool kRegs = (A_CT == 4);                     // upstream gradient stays in registers between the phases
+    const int A = A_CT > 0 ? A_CT : p.numAttr;
+    unsigned long long* s_vals = (unsigned long long*)s_mem;
+    uint32_t* s_keys = (uint32_t*)(s_mem + (size_t)slots * A * 8);
+    uint32_t* s_max = s_keys + slots;
+    int bx, by, pz;
+    if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
+    VertexTable tab{s_keys, s_vals, slots, A};
+    tab.clear(threadIdx.x, kIpThreads);
+    if (threadIdx.x == 0) *s_max = 0u;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = bx * kIpBlockW + lane;
+    const int row0 = by * kIpBlockH + wave * kIpRowsPerWave;
+    const size_t voff = (p.instance_mode && !p.attrBC) ? (size_t)pz * p.numVertices : 0;
+    const float* attr = p.attr + voff * A;
+    float* gattr = p.gradAttr + voff * A;
+
+    IpPixel q[kIpRowsPerWave];
+    bool ok[kIpRowsPerWave];
+    float4 yreg[kIpRowsPerWave];
+    float m = 0.f;
+
+    // ---- phase A -----------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < kIpRowsPerWave; r++) {
+        const int py = row0 + r;
+        ok[r] = false;
+        yreg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (py >= p.height || px >= p.width) continue;
+        const size_t pidx = ((size_t)pz * p.height + py) * p.width + px;
+        const float4 rr = ((const float4*)p.rast)[pidx];
+        const int triIdx = float_to_triidx(rr.w) - 1;
         if (triIdx < 0 || triIdx >= p.numTriangles) {
             ((float4*)p.gradRaster)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ENABLE_DA) ((float4*)p.gradRasterDB)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else {
-            vi0 = p.tri[triIdx * 3 + 0]; vi1 = p.tri[triIdx * 3 + 1]; vi2 = p.tri[triIdx * 3 + 2];
-            active = !(vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices);
+            continue;
         }
-    }
-    if (__ballot(active) == 0) return;
+        const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
+        if (vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices)
+            continue;                                       // corrupt indices: leave untouched (:163-167)
+        ok[r] = true;
+        q[r].tri = triIdx; q[r].vi0 = vi0; q[r].vi1 = vi1; q[r].vi2 = vi2; q[r].b0 = rr.x; q[r].b1 = rr.y;
+        const float* a0 = attr + (size_t)vi0 * A;
+        const float* a1 = attr + (size_t)vi1 * A;
+        const float* a2 = attr + (size_t)vi2 * A;
+        const float* pdy = p.dy + pidx * A;
+        const float bmax = fmaxf(fmaxf(fabsf(rr.x), fabsf(rr.y)), fabsf(1.f - rr.x - rr.y));
 
-    if (p.instance_mode && !p.attrBC) { vi0 += pz * p.numVertices; vi1 += pz * p.numVertices; vi2 += pz * p.numVertices; }
-    const float* a0 = p.attr + (size_t)vi0 * A;
-    const float* a1 = p.attr + (size_t)vi1 * A;
-    const float* a2 = p.attr + (size_t)vi2 * A;
-    const float* pdy = p.dy + pidx * A;
-    const float b0 = r.x, b1 = r.y, b2 = 1.f - r.x - r.y;
-
-    // Per-pixel part: gradients w.r.t. the barycentrics (and their pixel differentials).
-    float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) {
-        float gb0 = 0.f, gb1 = 0.f;
-        for (int i = 0; i < A; i++) {
-            float y = pdy[i];
-            float s2 = a2[i];
-            gb0 += y * (a0[i] - s2);
-            gb1 += y * (a1[i] - s2);
+        float gb0 = 0.f, gb1 = 0.f, ymax = 0.f;
+        if (kRegs) {
+            const float4 y = *(const float4*)pdy;
+            const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
+            gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
+            gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
+            ymax = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y), y.z), y.w);
+            yreg[r] = y;
+        } else {
+            for (int i = 0; i < A; i++) {
+                const float y = pdy[i];
+                const float s2v = a2[i];
+                gb0 += y * (a0[i] - s2v);
+                gb1 += y * (a1[i] - s2v);
+                ymax = max_abs_keep_nan(ymax, y);
+            }
         }
         ((float4*)p.gradRaster)[pidx] = make_float4(gb0, gb1, 0.f, 0.f);
+        m = max_abs_keep_nan(m, ymax * bmax);               // >= every |b_k * dy_i| (rounding is monotone)
+
         if (ENABLE_DA) {
-            db = ((const float4*)p.rastDB)[pidx];
+            const float4 db = ((const float4*)p.rastDB)[pidx];
             const float2* dda = ((const float2*)p.dda) + pidx * p.numDiffAttr;
             float gdudx = 0.f, gdudy = 0.f, gdvdx = 0.f, gdvdy = 0.f;
             for (int i = 0; i < p.numDiffAttr; i++) {
-                int j = diff_index(p, i);
+                const int j = diff_index(p, i);
                 if (j < 0) continue;
-                float2 d = dda[i];
-                float dsdu = a0[j] - a2[j], dsdv = a1[j] - a2[j];
+                const float2 d = dda[i];
+                const float dsdu = a0[j] - a2[j], dsdv = a1[j] - a2[j];
                 gdudx += dsdu * d.x; gdudy += dsdu * d.y;
                 gdvdx += dsdv * d.x; gdvdy += dsdv * d.y;
+                const float du = d.x * db.x + d.y * db.y;
+                const float dv = d.x * db.z + d.y * db.w;
+                m = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(m, du), dv), -du - dv);
             }
             ((float4*)p.gradRasterDB)[pidx] = make_float4(gdudx, gdudy, gdvdx, gdvdy);
         }
     }
+    block_max_update(s_max, m);
+    __syncthreads();
+    const uint32_t maxBits = *s_max;
+    if (maxBits == 0u || (p.dbg & 1)) return;               // no contribution anywhere in the block
+    const bool direct = maxBits >= 0x7F800000u;             // inf/NaN present: plain f32 atomics keep the semantics
+    const FixedScale fs(direct ? 0x3F800000u : maxBits);
 
-    // Attribute gradients: one atomic per (triangle, vertex, attribute) per wave.
-    const bool foldDA = ENABLE_DA && p.diff_attrs_all;           // diff attr i == attr i: fold into one pass
-    GroupIter it(active, triIdx);
-    while (it.next()) {
-        const int w0 = it.bcast(vi0), w1 = it.bcast(vi1), w2 = it.bcast(vi2);
-        float* g0 = p.gradAttr + (size_t)w0 * A;
-        float* g1 = p.gradAttr + (size_t)w1 * A;
-        float* g2 = p.gradAttr + (size_t)w2 * A;
+    // ---- phase B -----------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < kIpRowsPerWave; r++) {
+        if (__ballot(ok[r]) == 0) continue;
+        const RunScan rs(q[r].tri, ok[r]);
+        const bool emit = direct ? ok[r] : rs.tail;
+        int s0 = -1, s1 = -1, s2 = -1;
+        if (emit && !direct) { s0 = tab.find(q[r].vi0); s1 = tab.find(q[r].vi1); s2 = tab.find(q[r].vi2); }
+        auto put = [&](int slot, int vi, int i, float v) {
+            if (slot >= 0) tab.add(slot, i, fs.to_fixed(v));
+            else atomic_add_f32(gattr + (size_t)vi * A + i, v);
+        };
+        const float b0 = ok[r] ? q[r].b0 : 0.f, b1 = ok[r] ? q[r].b1 : 0.f, b2 = ok[r] ? 1.f - q[r].b0 - q[r].b1 : 0.f;
+        const size_t pidx = ((size_t)pz * p.height + (row0 + r)) * p.width + px;
+        const float* pdy = p.dy + pidx * A;
         for (int i = 0; i < A; i++) {
-            float y = it.member ? pdy[i] : 0.f;
-            float c0 = b0 * y, c1 = b1 * y, c2 = b2 * y;
-            if (foldDA && it.member) {
-                float2 d = (((const float2*)p.dda) + pidx * p.numDiffAttr)[i];
+            float y;
+            if (kRegs) y = i == 0 ? yreg[r].x : i == 1 ? yreg[r].y : i == 2 ? yreg[r].z : yreg[r].w;
+            else       y = ok[r] ? pdy[i] : 0.f;
+            float v0 = b0 * y, v1 = b1 * y, v2 = b2 * y;
+            if (!direct) rs.scan3(v0, v1, v2);
+            if (emit) { put(s0, q[r].vi0, i, v0); put(s1, q[r].vi1, i, v1); put(s2, q[r].vi2, i, v2); }
+        }
+        if (ENABLE_DA) {
+            float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[r]) db = ((const float4*)p.rastDB)[pidx];
+            const float2* dda = ((const float2*)p.dda) + pidx * p.numDiffAttr;
+            for (int i = 0; i < p.numDiffAttr; i++) {
+                const int j = diff_index(p, i);
+                if (j < 0) continue;
+                float2 d = make_float2(0.f, 0.f);
+                if (ok[r]) d = dda[i];
                 float du = d.x * db.x + d.y * db.y;
                 float dv = d.x * db.z + d.y * db.w;
-                c0 += du; c1 += dv; c2 += -du - dv;
+                float dw = -du - dv;
+                if (!direct) rs.scan3(du, dv, dw);
+                if (emit) { put(s0, q[r].vi0, j, du); put(s1, q[r].vi1, j, dv); put(s2, q[r].vi2, j, dw); }
             }
-            float s0 = (p.dbg & 2) ? c0 : it.sum(c0), s1 = (p.dbg & 2) ? c1 : it.sum(c1), s2 = (p.dbg & 2) ? c2 : it.sum(c2);
-            if (it.writer() && !(p.dbg & 1)) { atomic_add_f32(g0 + i, s0); atomic_add_f32(g1 + i, s1); atomic_add_f32(g2 + i, s2); }
         }
-        if (ENABLE_DA && !foldDA) {
-            for (int i = 0; i < p.numDiffAttr; i++) {
-                int j = diff_index(p, i);                         // uniform
-                if (j < 0) continue;
-                float du = 0.f, dv = 0.f;
-                if (it.member) {
-                    float2 d = (((const float2*)p.dda) + pidx * p.numDiffAttr)[i];
-                    du = d.x * db.x + d.y * db.y;
-                    dv = d.x * db.z + d.y * db.w;
-                }
-                float s0 = it.sum(du), s1 = it.sum(dv), s2 = it.sum(-du - dv);
-                if (it.writer()) { atomic_add_f32(g0 + j, s0); atomic_add_f32(g1 + j, s1); atomic_add_f32(g2 + j, s2); }
-            }
+    }
+    if (direct) return;
+
+    // Flush: one atomic per (vertex, attribute) this block touched.
+    __syncthreads();
+    const int n = slots * A;
+    for (int i = threadIdx.x; i < n; i += kIpThreads) {
+        const int slot = i / A;
+        const uint32_t key = s_keys[slot];
+        if (key) {
+            const unsigned long long t = s_vals[i];
+            if (t) atomic_add_f32(gattr + (size_t)(key - 1u) * A + (i - slot * A), fs.to_float(t));
         }
     }
 }
@@ -287,12 +361,25 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
     NVDR_REQUIRE(!((uintptr_t)g_rast_db & 15), "grad_rast_db output tensor not aligned to float4");
     p.dy = dy; p.dda = enable_da ? dda : nullptr;
     p.gradAttr = g_attr; p.gradRaster = g_rast; p.gradRasterDB = enable_da ? g_rast_db : nullptr;
-    dim3 grid((W + 31) / 32, (H + 7) / 8, N), block(256);
+    const int gx = (W + kIpBlockW - 1) / kIpBlockW, gy = (H + kIpBlockH - 1) / kIpBlockH;
+    const long long total = (long long)gx * gy * N;
+    NVDR_REQUIRE(total < (1ll << 30), "interpolate_grad: too many pixel blocks");
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kIpThreads);
+    // LDS vertex table: as many power-of-two slots as fit in 40 KiB, at most 1024.
+    int slots = 1024;
+    while (slots > 32 && (size_t)slots * (8 * A + 4) > 40 * 1024) slots >>= 1;
+    const size_t lds = (size_t)slots * (8 * A + 4) + 16;
+    NVDR_REQUIRE(lds <= 64 * 1024, "interpolate_grad: too many attributes (%d) for the LDS accumulator", A);
+    const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);
     {
         ProfileScope ps(enable_da ? "interp_grad_da" : "interp_grad", stream);
-        if (enable_da) hipLaunchKernelGGL((k_interp_grad<0, true>),  grid, block, 0, stream, p);
-        else if (A == 4) hipLaunchKernelGGL((k_interp_grad<4, false>), grid, block, 0, stream, p);
-        else           hipLaunchKernelGGL((k_interp_grad<0, false>), grid, block, 0, stream, p);
+        if (enable_da) {
+            if (vec4) hipLaunchKernelGGL((k_interp_grad<4, true>), grid, block, lds, stream, p, slots, gx, gy);
+            else      hipLaunchKernelGGL((k_interp_grad<0, true>), grid, block, lds, stream, p, slots, gx, gy);
+        } else {
+            if (vec4) hipLaunchKernelGGL((k_interp_grad<4, false>), grid, block, lds, stream, p, slots, gx, gy);
+            else      hipLaunchKernelGGL((k_interp_grad<0, false>), grid, block, lds, stream, p, slots, gx, gy);
+        }
     }
     NVDR_LAUNCH_CHECK();
     return NVDR_OK;

@@ -43,6 +43,22 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
 // Hardware f32 atomic add, no return value (global_atomic_add_f32).
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// XCD-aware decode of a 1-D grid into (block x, block y, image): blocks b, b+8, ... share an XCD
+// and walk a contiguous chunk of the (image-major) work list.
+__device__ __forceinline__ bool decode_block(int gx, int gy, int N, int& bx, int& by, int& pz)
+{
+    const int total = gx * gy * N;
+    const int perXcd = (total + 7) >> 3;
+    const int j = (int)(blockIdx.x >> 3);
+    const int item = (int)(blockIdx.x & 7) * perXcd + j;
+    if (j >= perXcd || item >= total) return false;
+    pz = item / (gx * gy);
+    const int rem = item - pz * (gx * gy);
+    by = rem / gx;
+    bx = rem - by * gx;
+    return true;
+}
+
 // ---- triangle-id <-> f32 codec (reference csrc/common/common.h:186-193) ----------
 // Identity up to 2^24; above that the id is stored as a bit-offset float so that it
 // survives the f32 channel.
@@ -91,6 +107,145 @@ struct GroupIter {
     __device__ __forceinline__ bool writer() const { return lane_id() == 63; }
     // Broadcast a per-lane int from the group's leader to all lanes.
     __device__ __forceinline__ int bcast(int v) const { return __builtin_amdgcn_readlane(v, leader); }
+};
+
+// ---- per-workgroup vertex accumulator ------------------------------------------------
+// Gradient scatter for the backward kernels.  Measured on MI355X (tools/lds_atomic_bench.hip):
+// global f32 atomics sustain ~21 G lane-ops/s however they are packed (they execute at the
+// memory side: the per-XCD L2s are not coherent), LDS ds_add_f32 costs ~200 cycles per wave
+// instruction, while LDS 64-bit INTEGER atomics cost ~7 cycles (+7 per same-address lane).
+// So a workgroup owns a block of pixels and an LDS open-addressing table keyed by vertex
+// index.  Contributions are first summed over runs of equal triangle id inside the wave
+// (RunScan: pixels of one triangle are contiguous in a scan line), the run totals are added
+// to the table in 64-bit fixed point with ds_add_u64, and each touched (vertex, component)
+// is flushed once with a hardware global f32 atomic.
+//
+// Fixed point: x -> round(x * 2^s) with the power of two s chosen per block from the largest
+// contribution magnitude M (M < 2^(e+1)  =>  s = 45 - e), so that a run total (<= 16 terms)
+// stays below 2^51 and the table sums (<= 2^13 terms) far below 2^63.  Every contribution is
+// represented to 2^-46 * M -- finer than an f32 sum of the same terms could resolve -- and
+// the integer sum is order independent.  Vertices that cannot be placed (table full) and
+// blocks holding inf/NaN fall back to direct global atomics, so any input is handled.
+
+__device__ __forceinline__ float wave_max_to_last(float v) {        // v >= 0; result valid in lane 63
+    v = fmaxf(v, dpp_move0<0xb1>(v));
+    v = fmaxf(v, dpp_move0<0x4e>(v));
+    v = fmaxf(v, dpp_move0<0x114>(v));
+    v = fmaxf(v, dpp_move0<0x118>(v));
+    v = fmaxf(v, dpp_move0<0x142, 0xa>(v));
+    v = fmaxf(v, dpp_move0<0x143, 0xc>(v));
+    return v;
+}
+
+// Publish a wave's largest magnitude to the workgroup.  `m` >= 0 or NaN per lane; NaN/inf end
+// up as a bit pattern >= 0x7F800000 (uint compare == float compare for non-negative floats).
+__device__ __forceinline__ void block_max_update(uint32_t* s_max, float m) {
+    if (__ballot(m != 0.f) == 0) return;                            // NaN != 0 is true
+    uint32_t bits = (uint32_t)__float_as_int(m) & 0x7FFFFFFFu;
+    float mm = wave_max_to_last(__int_as_float((int)min(bits, 0x7F800000u)));
+    if (lane_id() == 63) atomicMax(s_max, (uint32_t)__float_as_int(mm));
+}
+
+// max(|a|, m) that keeps NaN visible (fmaxf would drop it).
+__device__ __forceinline__ float max_abs_keep_nan(float m, float a) {
+    float r = fmaxf(m, fabsf(a));
+    return (a != a) ? a : r;
+}
+
+struct FixedScale {
+    double scale, inv;
+    __device__ __forceinline__ explicit FixedScale(uint32_t max_bits) {
+        const int e = (int)(max_bits >> 23) - 127;                   // M < 2^(e+1)
+        scale = __longlong_as_double((long long)(1023 + 45 - e) << 52);
+        inv   = __longlong_as_double((long long)(1023 - 45 + e) << 52);
+    }
+    // round-to-nearest-even of x * 2^s as a two's complement 64-bit integer: adding 1.5 * 2^52
+    // leaves the integer in the low mantissa bits of the double (|x * 2^s| < 2^51).
+    __device__ __forceinline__ unsigned long long to_fixed(float x) const {
+        const double d = __fma_rn((double)x, scale, 6755399441055744.0);
+        return (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
+    }
+    __device__ __forceinline__ float to_float(unsigned long long t) const {
+        return (float)((double)(long long)t * inv);
+    }
+};
+
+// Segmented inclusive scan over runs of equal `key` among consecutive active lanes, limited to
+// the 16-lane DPP rows (a run that crosses a row boundary simply yields two totals).  After
+// scan(v) the last lane of every run (`tail`) holds the run's sum.
+struct RunScan {
+    float c1, c2, c4, c8;
+    bool  tail;
+    __device__ __forceinline__ RunScan(int key, bool active) {
+        const int lane = lane_id();
+        if (!active) key = -1;
+        const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x111, 0xf, 0xf, false);   // row_shr:1
+        const bool head = (prev != key) | !active;
+        const uint64_t H = __ballot(head) | 0x0001000100010001ull;
+        const uint64_t below = H & ((2ull << lane) - 1ull);                                // heads at or below me
+        const int dist = lane - (63 - __builtin_clzll(below));
+        c1 = dist >= 1 ? 1.f : 0.f; c2 = dist >= 2 ? 1.f : 0.f;
+        c4 = dist >= 4 ? 1.f : 0.f; c8 = dist >= 8 ? 1.f : 0.f;
+        tail = active && (lane == 63 || ((H >> (lane + 1)) & 1ull));
+    }
+    template <int CTRL> static __device__ __forceinline__ float shr(float v) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    }
+    // Three scans at once with the DPP source folded into the multiply-add (the compiler keeps
+    // v_mov_dpp + v_fma apart); interleaving the three chains covers the 2 wait states a DPP read
+    // needs after a VALU write of its source, the leading s_nop covers a preceding EXEC/VGPR write.
+    __device__ __forceinline__ void scan3(float& a, float& b, float& c) const {
+        asm volatile(
+            "s_nop 4\n"
+            "v_fmac_f32_dpp %0, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %1, %1, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %2, %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %0, %0, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %1, %1, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %2, %2, %4 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %0, %0, %5 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %1, %1, %5 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %2, %2, %5 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %0, %0, %6 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %1, %1, %6 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            "v_fmac_f32_dpp %2, %2, %6 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+            : "+v"(a), "+v"(b), "+v"(c) : "v"(c1), "v"(c2), "v"(c4), "v"(c8));
+    }
+    __device__ __forceinline__ float scan(float v) const {
+        v = __fmaf_rn(shr<0x111>(v), c1, v);
+        v = __fmaf_rn(shr<0x112>(v), c2, v);
+        v = __fmaf_rn(shr<0x114>(v), c4, v);
+        v = __fmaf_rn(shr<0x118>(v), c8, v);
+        return v;
+    }
+};
+
+struct VertexTable {
+    uint32_t*           keys;    // [slots]   0 = empty, else vertex + 1
+    unsigned long long* vals;    // [slots * stride] fixed-point sums
+    int                 slots;   // power of two
+    int                 stride;  // components per vertex
+
+    __device__ __forceinline__ void clear(int tid, int nthreads) {
+        for (int i = tid; i < slots; i += nthreads) keys[i] = 0u;
+        for (int i = tid; i < slots * stride; i += nthreads) vals[i] = 0ull;
+    }
+    // Slot of `vertex` (inserting it if needed) or -1 when the probe budget is exhausted.
+    __device__ __forceinline__ int find(int vertex) const {
+        const uint32_t key = (uint32_t)vertex + 1u;
+        uint32_t h = (key * 0x9E3779B1u) >> 8;
+#pragma unroll 1
+        for (int probe = 0; probe < 16; probe++) {
+            h &= (uint32_t)(slots - 1);
+            uint32_t old = atomicCAS(&keys[h], 0u, key);
+            if (old == 0u || old == key) return (int)h;
+            h++;
+        }
+        return -1;
+    }
+    __device__ __forceinline__ void add(int slot, int comp, unsigned long long v) const {
+        atomicAdd(&vals[slot * stride + comp], v);
+    }
 };
 
 }  // namespace nvdr

@@ -25,7 +25,8 @@
 //            atomics and no colour/depth surface.  The winning id goes straight into the
 //            pixel shader (rasterize.cu:15-114) in the same kernel, so the id/depth
 //            surfaces never touch HBM (the depth surface is stored only for depth peeling).
-//  k_grad    rasterize.cu:119-277 with DPP-reduced, triangle-grouped atomics.
+//  k_grad    rasterize.cu:119-277; gradients are accumulated per vertex in an LDS fixed-point hash
+//            table per 64x64 pixel block and flushed with one hardware atomic per (vertex, component).
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
 
@@ -725,129 +726,208 @@ struct GradParams {
     int dbg;
 };
 
-// Block = 4 waves, each wave an 8x8 pixel tile (keeps a triangle's pixels in one wave so the
-// grouped reduction collapses most of its atomics).
+// Workgroup = 64 x 32 pixel block of one image, 8 waves, each wave owning four 64-pixel rows
+// (1 KiB coalesced loads of rast / dy, all four rows in flight together).  The per-pixel
+// gradients stay in registers between the two phases:
+//   A  compute them, publish the block's largest magnitude (fixes the fixed-point scale);
+//   B  sum them over runs of equal triangle id inside the wave (RunScan), add the run totals to
+//      the workgroup's LDS vertex table (nvdr_device.hpp) with ds_add_u64, then flush one global
+//      atomic per (vertex, x|y|w) the block touched.
+// Work order: block b runs on XCD b % 8 (observed placement, speed only); an image's blocks are
+// given to one XCD so that its vertices / indices are fetched into one L2.
+constexpr int kGradBlockW = 64;
+constexpr int kGradBlockH = 32;
+constexpr int kGradThreads = 512;
+constexpr int kGradRowsPerWave = 4;
+constexpr int kGradSlots = 1024;
+
+struct PixelGrad { int tri, vi0, vi1, vi2; float g[9]; };
+
 template <bool ENABLE_DB>
-__global__ __launch_bounds__(256) void k_raster_grad(const GradParams p)
+__device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const float4* __restrict__ vb, int px, int py, int pz, PixelGrad& r)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = (blockIdx.x * 4 + wave) * 8 + (lane & 7);
-    const int py = blockIdx.y * 8 + (lane >> 3);
-    const int pz = blockIdx.z;
-    bool active = (px < p.W) && (py < p.H);
-
-    int triIdx = -1, vi0 = 0, vi1 = 0, vi2 = 0;
-    float2 dy = make_float2(0.f, 0.f);
+    if (px >= p.W) return false;
+    const size_t pidx = ((size_t)pz * p.H + py) * p.W + px;
+    const float4 o = ((const float4*)p.out)[pidx];
+    const float4 d = ((const float4*)p.dy)[pidx];
+    const float2 dy = make_float2(d.x, d.y);
     float4 ddb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ENABLE_DB) ddb = ((const float4*)p.ddb)[pidx];
+    const int triIdx = float_to_triidx(o.w) - 1;
+    if (triIdx < 0 || triIdx >= p.T) return false;
+    const int grad_all_dy = __float_as_int(dy.x) | __float_as_int(dy.y);
     int grad_all_ddb = 0;
-    if (active) {
-        size_t pidx = ((size_t)pz * p.H + py) * p.W + px;
-        float4 o = ((const float4*)p.out)[pidx];
-        float4 d = ((const float4*)p.dy)[pidx];
-        dy = make_float2(d.x, d.y);
-        if (ENABLE_DB) ddb = ((const float4*)p.ddb)[pidx];
-        triIdx = float_to_triidx(o.w) - 1;
-        active = (triIdx >= 0 && triIdx < p.T);
-        int grad_all_dy = __float_as_int(dy.x) | __float_as_int(dy.y);
-        if (ENABLE_DB) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
-        if ((((uint32_t)(grad_all_dy | grad_all_ddb)) << 1) == 0u) active = false;      // all +-0 (:143-148)
+    if (ENABLE_DB) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
+    if ((((uint32_t)(grad_all_dy | grad_all_ddb)) << 1) == 0u) return false;          // all +-0 (:143-148)
+    const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
+    if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) return false;
+    r.tri = triIdx; r.vi0 = vi0; r.vi1 = vi1; r.vi2 = vi2;
+
+    const float4 p0 = vb[vi0], p1 = vb[vi1], p2 = vb[vi2];
+    const float fx = p.xs * (float)px + p.xo;
+    const float fy = p.ys * (float)py + p.yo;
+    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    const float a0 = p1x * p2y - p1y * p2x;
+    const float a1 = p2x * p0y - p2y * p0x;
+    const float a2 = p0x * p1y - p0y * p1x;
+
+    const float at = a0 + a1 + a2;
+    const float ep = copysignf(1e-6f, at);
+    const float iw = 1.f / (at + ep);
+    const float b0 = a0 * iw, b1 = a1 * iw;
+
+    const float gb0 = dy.x * iw, gb1 = dy.y * iw;
+    const float gbb = gb0 * b0 + gb1 * b1;
+    float gp0x = gbb * (p2y - p1y) - gb1 * p2y;
+    float gp1x = gbb * (p0y - p2y) + gb0 * p2y;
+    float gp2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+    float gp0y = gbb * (p1x - p2x) + gb1 * p2x;
+    float gp1y = gbb * (p2x - p0x) - gb0 * p2x;
+    float gp2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+    float gp0w = -fx * gp0x - fy * gp0y;
+    float gp1w = -fx * gp1x - fy * gp1y;
+    float gp2w = -fx * gp2x - fy * gp2y;
+
+    if (ENABLE_DB && (((uint32_t)grad_all_ddb) << 1) != 0u) {
+        const float dfxdX = p.xs * iw, dfydY = p.ys * iw;
+        ddb.x *= dfxdX; ddb.y *= dfydY; ddb.z *= dfxdX; ddb.w *= dfydY;
+
+        const float da0dX = p1.y * p2.w - p2.y * p1.w;
+        const float da1dX = p2.y * p0.w - p0.y * p2.w;
+        const float da2dX = p0.y * p1.w - p1.y * p0.w;
+        const float da0dY = p2.x * p1.w - p1.x * p2.w;
+        const float da1dY = p0.x * p2.w - p2.x * p0.w;
+        const float da2dY = p1.x * p0.w - p0.x * p1.w;
+        const float datdX = da0dX + da1dX + da2dX;
+        const float datdY = da0dY + da1dY + da2dY;
+
+        const float x01 = p0.x - p1.x, x12 = p1.x - p2.x, x20 = p2.x - p0.x;
+        const float y01 = p0.y - p1.y, y12 = p1.y - p2.y, y20 = p2.y - p0.y;
+        const float w01 = p0.w - p1.w, w12 = p1.w - p2.w, w20 = p2.w - p0.w;
+
+        const float a0p1 = fy * p2.x - fx * p2.y;
+        const float a0p2 = fx * p1.y - fy * p1.x;
+        const float a1p0 = fx * p2.y - fy * p2.x;
+        const float a1p2 = fy * p0.x - fx * p0.y;
+
+        const float wdudX = 2.f * b0 * datdX - da0dX;
+        const float wdudY = 2.f * b0 * datdY - da0dY;
+        const float wdvdX = 2.f * b1 * datdX - da1dX;
+        const float wdvdY = 2.f * b1 * datdY - da1dY;
+
+        const float c0  = iw * (ddb.x * wdudX + ddb.y * wdudY + ddb.z * wdvdX + ddb.w * wdvdY);
+        const float cx  = c0 * fx - ddb.x * b0 - ddb.z * b1;
+        const float cy  = c0 * fy - ddb.y * b0 - ddb.w * b1;
+        const float cxy = iw * (ddb.x * datdX + ddb.y * datdY);
+        const float czw = iw * (ddb.z * datdX + ddb.w * datdY);
+
+        gp0x += c0 * y12 - cy * w12 + czw * p2y + ddb.w * p2.w;
+        gp1x += c0 * y20 - cy * w20 - cxy * p2y - ddb.y * p2.w;
+        gp2x += c0 * y01 - cy * w01 + cxy * p1y - czw * p0y + ddb.y * p1.w - ddb.w * p0.w;
+        gp0y += cx * w12 - c0 * x12 - czw * p2x - ddb.z * p2.w;
+        gp1y += cx * w20 - c0 * x20 + cxy * p2x + ddb.x * p2.w;
+        gp2y += cx * w01 - c0 * x01 - cxy * p1x + czw * p0x - ddb.x * p1.w + ddb.z * p0.w;
+        gp0w += cy * x12 - cx * y12 - czw * a1p0 + ddb.z * p2.y - ddb.w * p2.x;
+        gp1w += cy * x20 - cx * y20 - cxy * a0p1 - ddb.x * p2.y + ddb.y * p2.x;
+        gp2w += cy * x01 - cx * y01 - cxy * a0p2 - czw * a1p2 + ddb.x * p1.y - ddb.y * p1.x - ddb.z * p0.y + ddb.w * p0.x;
     }
-    if (active) {
-        vi0 = p.tri[triIdx * 3 + 0]; vi1 = p.tri[triIdx * 3 + 1]; vi2 = p.tri[triIdx * 3 + 2];
-        if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) active = false;
-    }
-    if (__ballot(active) == 0) return;
+    r.g[0] = gp0x; r.g[1] = gp0y; r.g[2] = gp0w;
+    r.g[3] = gp1x; r.g[4] = gp1y; r.g[5] = gp1w;
+    r.g[6] = gp2x; r.g[7] = gp2y; r.g[8] = gp2w;
+    return true;
+}
 
-    float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (active) {
-        if (p.instance) { vi0 += pz * p.V; vi1 += pz * p.V; vi2 += pz * p.V; }
-        float4 p0 = ((const float4*)p.pos)[vi0], p1 = ((const float4*)p.pos)[vi1], p2 = ((const float4*)p.pos)[vi2];
-        float fx = p.xs * (float)px + p.xo;
-        float fy = p.ys * (float)py + p.yo;
-        float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-        float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-        float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-        float a0 = p1x * p2y - p1y * p2x;
-        float a1 = p2x * p0y - p2y * p0x;
-        float a2 = p0x * p1y - p0y * p1x;
+template <bool ENABLE_DB>
+__global__ __launch_bounds__(kGradThreads) void k_raster_grad(const GradParams p, int gx, int gy)
+{
+    __shared__ uint32_t s_keys[kGradSlots];
+    __shared__ unsigned long long s_vals[kGradSlots * 3];
+    __shared__ uint32_t s_max;
+    int bx, by, pz;
+    if (!decode_block(gx, gy, p.N, bx, by, pz)) return;
+    VertexTable tab{s_keys, s_vals, kGradSlots, 3};
+    tab.clear(threadIdx.x, kGradThreads);
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
 
-        float at = a0 + a1 + a2;
-        float ep = copysignf(1e-6f, at);
-        float iw = 1.f / (at + ep);
-        float b0 = a0 * iw, b1 = a1 * iw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = bx * kGradBlockW + lane;
+    const int row0 = by * kGradBlockH + wave * kGradRowsPerWave;
+    const size_t voff = p.instance ? (size_t)pz * p.V : 0;
+    const float4* vb = (const float4*)p.pos + voff;
+    float* gout = p.grad + voff * 4;
 
-        float gb0 = dy.x * iw, gb1 = dy.y * iw;
-        float gbb = gb0 * b0 + gb1 * b1;
-        float gp0x = gbb * (p2y - p1y) - gb1 * p2y;
-        float gp1x = gbb * (p0y - p2y) + gb0 * p2y;
-        float gp2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
-        float gp0y = gbb * (p1x - p2x) + gb1 * p2x;
-        float gp1y = gbb * (p2x - p0x) - gb0 * p2x;
-        float gp2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-        float gp0w = -fx * gp0x - fy * gp0y;
-        float gp1w = -fx * gp1x - fy * gp1y;
-        float gp2w = -fx * gp2x - fy * gp2y;
-
-        if (ENABLE_DB && (((uint32_t)grad_all_ddb) << 1) != 0u) {
-            float dfxdX = p.xs * iw, dfydY = p.ys * iw;
-            ddb.x *= dfxdX; ddb.y *= dfydY; ddb.z *= dfxdX; ddb.w *= dfydY;
-
-            float da0dX = p1.y * p2.w - p2.y * p1.w;
-            float da1dX = p2.y * p0.w - p0.y * p2.w;
-            float da2dX = p0.y * p1.w - p1.y * p0.w;
-            float da0dY = p2.x * p1.w - p1.x * p2.w;
-            float da1dY = p0.x * p2.w - p2.x * p0.w;
-            float da2dY = p1.x * p0.w - p0.x * p1.w;
-            float datdX = da0dX + da1dX + da2dX;
-            float datdY = da0dY + da1dY + da2dY;
-
-            float x01 = p0.x - p1.x, x12 = p1.x - p2.x, x20 = p2.x - p0.x;
-            float y01 = p0.y - p1.y, y12 = p1.y - p2.y, y20 = p2.y - p0.y;
-            float w01 = p0.w - p1.w, w12 = p1.w - p2.w, w20 = p2.w - p0.w;
-
-            float a0p1 = fy * p2.x - fx * p2.y;
-            float a0p2 = fx * p1.y - fy * p1.x;
-            float a1p0 = fx * p2.y - fy * p2.x;
-            float a1p2 = fy * p0.x - fx * p0.y;
-
-            float wdudX = 2.f * b0 * datdX - da0dX;
-            float wdudY = 2.f * b0 * datdY - da0dY;
-            float wdvdX = 2.f * b1 * datdX - da1dX;
-            float wdvdY = 2.f * b1 * datdY - da1dY;
-
-            float c0  = iw * (ddb.x * wdudX + ddb.y * wdudY + ddb.z * wdvdX + ddb.w * wdvdY);
-            float cx  = c0 * fx - ddb.x * b0 - ddb.z * b1;
-            float cy  = c0 * fy - ddb.y * b0 - ddb.w * b1;
-            float cxy = iw * (ddb.x * datdX + ddb.y * datdY);
-            float czw = iw * (ddb.z * datdX + ddb.w * datdY);
-
-            gp0x += c0 * y12 - cy * w12 + czw * p2y + ddb.w * p2.w;
-            gp1x += c0 * y20 - cy * w20 - cxy * p2y - ddb.y * p2.w;
-            gp2x += c0 * y01 - cy * w01 + cxy * p1y - czw * p0y + ddb.y * p1.w - ddb.w * p0.w;
-            gp0y += cx * w12 - c0 * x12 - czw * p2x - ddb.z * p2.w;
-            gp1y += cx * w20 - c0 * x20 + cxy * p2x + ddb.x * p2.w;
-            gp2y += cx * w01 - c0 * x01 - cxy * p1x + czw * p0x - ddb.x * p1.w + ddb.z * p0.w;
-            gp0w += cy * x12 - cx * y12 - czw * a1p0 + ddb.z * p2.y - ddb.w * p2.x;
-            gp1w += cy * x20 - cx * y20 - cxy * a0p1 - ddb.x * p2.y + ddb.y * p2.x;
-            gp2w += cy * x01 - cx * y01 - cxy * a0p2 - czw * a1p2 + ddb.x * p1.y - ddb.y * p1.x - ddb.z * p0.y + ddb.w * p0.x;
-        }
-        g[0] = gp0x; g[1] = gp0y; g[2] = gp0w;
-        g[3] = gp1x; g[4] = gp1y; g[5] = gp1w;
-        g[6] = gp2x; g[7] = gp2y; g[8] = gp2w;
-    }
-
-    // One atomic per (triangle, vertex, component) per wave instead of per pixel.
-    GroupIter it(active, triIdx);
-    while (it.next()) {
-        const int w0 = it.bcast(vi0), w1 = it.bcast(vi1), w2 = it.bcast(vi2);
-        float s[9];
+    // Phase A: per-pixel gradients (kept in registers) and the block's largest magnitude.
+    PixelGrad pg[kGradRowsPerWave];
+    bool ok[kGradRowsPerWave];
+    float m = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; k++) s[k] = (p.dbg & 2) ? g[k] : it.sum(g[k]);
-        if (it.writer() && !(p.dbg & 1)) {
-            float* q0 = p.grad + (size_t)w0 * 4; float* q1 = p.grad + (size_t)w1 * 4; float* q2 = p.grad + (size_t)w2 * 4;
-            atomic_add_f32(q0 + 0, s[0]); atomic_add_f32(q0 + 1, s[1]); atomic_add_f32(q0 + 3, s[2]);
-            atomic_add_f32(q1 + 0, s[3]); atomic_add_f32(q1 + 1, s[4]); atomic_add_f32(q1 + 3, s[5]);
-            atomic_add_f32(q2 + 0, s[6]); atomic_add_f32(q2 + 1, s[7]); atomic_add_f32(q2 + 3, s[8]);
+    for (int r = 0; r < kGradRowsPerWave; r++) {
+        const int py = row0 + r;
+        ok[r] = (py < p.H) && raster_pixel_grad<ENABLE_DB>(p, vb, px, py, pz, pg[r]);
+        if (ok[r]) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) m = max_abs_keep_nan(m, pg[r].g[k]);
+        } else {
+            pg[r].tri = -1;
+#pragma unroll
+            for (int k = 0; k < 9; k++) pg[r].g[k] = 0.f;       // the run scan multiplies masked lanes by 0: keep them finite
+        }
+    }
+    block_max_update(&s_max, m);
+    __syncthreads();
+    const uint32_t maxBits = s_max;
+    if (maxBits == 0u || (p.dbg & 1)) return;                    // nothing to accumulate
+
+    if (maxBits >= 0x7F800000u) {                                // inf/NaN present: plain f32 atomics keep the semantics
+#pragma unroll
+        for (int r = 0; r < kGradRowsPerWave; r++) {
+            if (!ok[r]) continue;
+            const int vi[3] = {pg[r].vi0, pg[r].vi1, pg[r].vi2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float* q = gout + (size_t)vi[k] * 4;
+                atomic_add_f32(q + 0, pg[r].g[k * 3 + 0]); atomic_add_f32(q + 1, pg[r].g[k * 3 + 1]); atomic_add_f32(q + 3, pg[r].g[k * 3 + 2]);
+            }
+        }
+        return;
+    }
+    const FixedScale fs(maxBits);
+
+    // Phase B: run totals -> LDS table.
+#pragma unroll
+    for (int r = 0; r < kGradRowsPerWave; r++) {
+        if (__ballot(ok[r]) == 0) continue;
+        const RunScan rs(pg[r].tri, ok[r]);
+#pragma unroll
+        for (int k = 0; k < 9; k += 3) rs.scan3(pg[r].g[k], pg[r].g[k + 1], pg[r].g[k + 2]);
+        if (rs.tail) {
+            const int vi[3] = {pg[r].vi0, pg[r].vi1, pg[r].vi2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int s = tab.find(vi[k]);
+                if (s >= 0) {
+                    tab.add(s, 0, fs.to_fixed(pg[r].g[k * 3 + 0]));
+                    tab.add(s, 1, fs.to_fixed(pg[r].g[k * 3 + 1]));
+                    tab.add(s, 2, fs.to_fixed(pg[r].g[k * 3 + 2]));
+                } else {
+                    float* q = gout + (size_t)vi[k] * 4;
+                    atomic_add_f32(q + 0, pg[r].g[k * 3 + 0]); atomic_add_f32(q + 1, pg[r].g[k * 3 + 1]); atomic_add_f32(q + 3, pg[r].g[k * 3 + 2]);
+                }
+            }
+        }
+    }
+
+    // Flush: one atomic per (vertex, component) this block touched.
+    __syncthreads();
+    for (int i = threadIdx.x; i < kGradSlots * 3; i += kGradThreads) {
+        const int slot = i / 3, c = i - slot * 3;
+        const uint32_t key = s_keys[slot];
+        if (key) {
+            const unsigned long long t = s_vals[i];
+            if (t) atomic_add_f32(gout + (size_t)(key - 1u) * 4 + (c == 2 ? 3 : c), fs.to_float(t));
         }
     }
 }
@@ -997,11 +1077,14 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
     p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
     p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
     p.dbg = debug_flags();
-    dim3 grid((W + 31) / 32, (H + 7) / 8, N);
+    const int gx = (W + kGradBlockW - 1) / kGradBlockW, gy = (H + kGradBlockH - 1) / kGradBlockH;
+    const long long total = (long long)gx * gy * N;
+    NVDR_REQUIRE(total < (1ll << 30), "rasterize_grad: too many pixel blocks");
+    dim3 grid((unsigned)(((total + 7) / 8) * 8));
     {
         ProfileScope ps(ddb ? "raster_grad_db" : "raster_grad", stream);
-        if (ddb) hipLaunchKernelGGL(k_raster_grad<true>,  grid, dim3(256), 0, stream, p);
-        else     hipLaunchKernelGGL(k_raster_grad<false>, grid, dim3(256), 0, stream, p);
+        if (ddb) hipLaunchKernelGGL(k_raster_grad<true>,  grid, dim3(kGradThreads), 0, stream, p, gx, gy);
+        else     hipLaunchKernelGGL(k_raster_grad<false>, grid, dim3(kGradThreads), 0, stream, p, gx, gy);
     }
     NVDR_LAUNCH_CHECK();
     return NVDR_OK;
