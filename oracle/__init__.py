@@ -173,3 +173,118 @@ def interpolate_grad(attr, rast, tri, dy, rast_db=None, dda=None, diff_attrs=Non
                                       _p(g_attr, _f32p), _p(g_rast, _f32p), _p(g_rdb, _f32p))
     assert rc == 0
     return g_attr, g_rast, g_rdb
+
+
+# --------------------------------------------------------------------------- texture
+
+_FILTER = {"nearest": 0, "linear": 1, "linear-mipmap-nearest": 2, "linear-mipmap-linear": 3}
+_BOUNDARY = {"cube": 0, "wrap": 1, "clamp": 2, "zero": 3}
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def texture_mip_info(tex_shape, max_mip_level=-1):
+    """-> (L, widths, heights, offsets_in_floats, total_floats); raises on odd extents (texture.cpp:85-86)."""
+    n, h, w, c = [int(x) for x in tex_shape]
+    lw = (ctypes.c_int * 17)(); lh = (ctypes.c_int * 17)(); off = (ctypes.c_int64 * 17)()
+    total = ctypes.c_int64(0)
+    L = lib().nvdro_texture_mip_info(n, h, w, c, 0, int(max_mip_level), lw, lh, off, ctypes.byref(total))
+    if L < 0:
+        raise ValueError("texture extents must be divisible by two at every mip level")
+    return L, list(lw[:L + 1]), list(lh[:L + 1]), list(off[:L + 1]), int(total.value)
+
+
+def texture_build_mip(tex, max_mip_level=-1):
+    """2x2 box mip chain -> list of arrays for levels 1..L, each [n,h,w,c] (views of one flat buffer)."""
+    tex = _f32(tex)
+    n, h, w, c = tex.shape
+    L, lw, lh, off, total = texture_mip_info(tex.shape, max_mip_level)
+    flat = np.zeros(max(total, 1), np.float32)
+    rc = lib().nvdro_texture_build_mip(_p(tex, _f32p), n, h, w, c, 0, int(max_mip_level), _p(flat, _f32p))
+    assert rc == 0
+    return [flat[off[i]:off[i] + n * lh[i] * lw[i] * c].reshape(n, lh[i], lw[i], c) for i in range(1, L + 1)]
+
+
+def _ptr_array(arrs):
+    n = max(len(arrs), 1)
+    pa = (_f32p * n)()
+    for i, a in enumerate(arrs):
+        pa[i] = a.ctypes.data_as(_f32p)
+    return pa
+
+
+def _texture_setup(tex, uv, uv_da, mip_level_bias, mip, filter_mode, boundary_mode, max_mip_level):
+    tex = _f32(tex); uv = _f32(uv)
+    if filter_mode == "auto":
+        filter_mode = "linear-mipmap-linear" if (uv_da is not None or mip_level_bias is not None) else "linear"
+    mml = -1 if max_mip_level is None else int(max_mip_level)
+    if mml == 0 and "mipmap" in filter_mode:
+        filter_mode = "linear"
+    levels = []
+    if "mipmap" in filter_mode:
+        assert uv_da is not None or mip_level_bias is not None
+        levels = [_f32(m) for m in mip] if mip is not None else texture_build_mip(tex, mml)
+    else:
+        uv_da = mip_level_bias = None
+    uv_da = None if uv_da is None else _f32(uv_da)
+    mip_level_bias = None if mip_level_bias is None else _f32(mip_level_bias)
+    return tex, uv, uv_da, mip_level_bias, levels, filter_mode, _FILTER[filter_mode], _BOUNDARY[boundary_mode]
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="auto", boundary_mode="wrap", max_mip_level=None):
+    """Arguments as nvdiffrast.torch.texture (2D textures); ``mip`` = optional list of level arrays."""
+    tex, uv, uv_da, bias, levels, _, f, b = _texture_setup(tex, uv, uv_da, mip_level_bias, mip, filter_mode, boundary_mode, max_mip_level)
+    N, H, W = uv.shape[:3]
+    out = np.empty((N, H, W, tex.shape[3]), np.float32)
+    pa = _ptr_array(levels)
+    rc = lib().nvdro_texture_fwd(_p(tex, _f32p), pa, len(levels), _p(uv, _f32p), _p(uv_da, _f32p), _p(bias, _f32p),
+                                 tex.shape[0], tex.shape[1], tex.shape[2], tex.shape[3], N, H, W, f, b, _p(out, _f32p))
+    assert rc == 0, rc
+    return out
+
+
+def texture_grad(tex, uv, dy, uv_da=None, mip_level_bias=None, mip=None, filter_mode="auto", boundary_mode="wrap", max_mip_level=None):
+    """-> dict(tex, uv, uv_da, mip_level_bias, mip).  With ``mip`` given (custom stack) the levels get their
+    own gradients (dict['mip']); otherwise mip gradients are folded into dict['tex'] like MipGradKernel."""
+    tex, uv, uv_da, bias, levels, fname, f, b = _texture_setup(tex, uv, uv_da, mip_level_bias, mip, filter_mode, boundary_mode, max_mip_level)
+    dy = _f32(dy)
+    N, H, W = uv.shape[:3]
+    custom = mip is not None and len(levels) > 0
+    g_tex = np.zeros_like(tex)
+    g_levels = [np.zeros_like(l) for l in levels]
+    g_uv = np.zeros_like(uv) if f != 0 else None
+    g_uv_da = np.zeros_like(uv_da) if (f == 3 and uv_da is not None) else None
+    g_bias = np.zeros_like(bias) if (f == 3 and bias is not None) else None
+    pa = _ptr_array(levels); ga = _ptr_array(g_levels)
+    rc = lib().nvdro_texture_grad(_p(tex, _f32p), pa, len(levels), _p(uv, _f32p), _p(uv_da, _f32p), _p(bias, _f32p),
+                                  _p(dy, _f32p), tex.shape[0], tex.shape[1], tex.shape[2], tex.shape[3], N, H, W, f, b,
+                                  int(not custom), _p(g_tex, _f32p), ga, _p(g_uv, _f32p), _p(g_uv_da, _f32p), _p(g_bias, _f32p))
+    assert rc == 0, rc
+    return dict(tex=g_tex, uv=g_uv, uv_da=g_uv_da, mip_level_bias=g_bias, mip=g_levels if custom else None)
+
+
+# --------------------------------------------------------------------------- antialias
+
+def antialias(color, rast, pos, tri):
+    color = _f32(color); rast = _f32(rast); pos = _f32(pos); tri = _i32(tri)
+    inst = pos.ndim == 3
+    N, H, W, C = color.shape
+    V = pos.shape[1] if inst else pos.shape[0]
+    out = np.empty_like(color)
+    rc = lib().nvdro_antialias_fwd(_p(color, _f32p), _p(rast, _f32p), _p(pos, _f32p), _p(tri, _i32p), int(inst),
+                                   N, V, tri.shape[0], H, W, C, _p(out, _f32p))
+    assert rc == 0, rc
+    return out
+
+
+def antialias_grad(color, rast, pos, tri, dy):
+    """-> (g_color, g_pos)"""
+    color = _f32(color); rast = _f32(rast); pos = _f32(pos); tri = _i32(tri); dy = _f32(dy)
+    inst = pos.ndim == 3
+    N, H, W, C = color.shape
+    V = pos.shape[1] if inst else pos.shape[0]
+    g_color = np.empty_like(color)
+    g_pos = np.empty_like(pos)
+    rc = lib().nvdro_antialias_grad(_p(color, _f32p), _p(rast, _f32p), _p(pos, _f32p), _p(tri, _i32p), _p(dy, _f32p),
+                                    int(inst), N, V, tri.shape[0], H, W, C, _p(g_color, _f32p), _p(g_pos, _f32p))
+    assert rc == 0, rc
+    return g_color, g_pos
