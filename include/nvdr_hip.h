@@ -93,6 +93,70 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
                           int diff_all, const int32_t* diff_attrs_host, int num_diff,
                           float* g_attr, float* g_rast, float* g_rast_db, nvdrStream_t stream);
 
+/* ---- texture --------------------------------------------------------------------
+ * Replaces texture_construct_mip / texture_fwd / texture_fwd_mip / texture_grad_nearest /
+ * texture_grad_linear / texture_grad_linear_mipmap_nearest / texture_grad_linear_mipmap_linear
+ * (torch_bindings.cpp:61-67; csrc/torch/torch_texture.cpp:98-716) for 2D textures.
+ * filter_mode: 0 nearest, 1 linear, 2 linear-mipmap-nearest, 3 linear-mipmap-linear;
+ * boundary_mode: 0 cube (rejected: not implemented), 1 wrap, 2 clamp, 3 zero (ops.py:415-420).
+ * tex [tex_n,tex_h,tex_w,C] with tex_n == N or 1; uv [N,H,W,2]; uv_da [N,H,W,4] or NULL;
+ * mip_level_bias [N,H,W] or NULL; out / dy [N,H,W,C]. */
+
+/* Mip geometry (pure host code; csrc/common/texture.cpp:62-102): fills widths / heights /
+ * offsets-in-floats (relative to the mip buffer; entry 0 is the base level, offset -1) for levels
+ * 0..L and returns L, or -1 when an extent cannot be halved (odd size above 1).  Arrays need 17
+ * entries; any of them may be NULL. */
+int nvdr_texture_mip_info(int tex_n, int tex_h, int tex_w, int C, int cube, int max_mip_level,
+                          int* lvl_w, int* lvl_h, int64_t* lvl_off, int64_t* total_floats);
+
+/* Builds levels 1..L into `mip` (total_floats from nvdr_texture_mip_info). */
+int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h, int tex_w, int C, int cube,
+                               int max_mip_level, float* mip, nvdrStream_t stream);
+
+/* mip_ptrs_host: HOST array of L device pointers (levels 1..L; the wrapper's flat buffer plus
+ * offsets, or the tensors of a custom stack); NULL / L = 0 for the non-mipmapped filters. */
+int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_host, int L,
+                     const float* uv, const float* uv_da, const float* mip_level_bias,
+                     int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
+                     int filter_mode, int boundary_mode, float* out, nvdrStream_t stream);
+
+/* g_tex (shape of tex) and every g_mip level must be zero-filled by the caller
+ * (torch_texture.cpp:523,583-604); g_uv [N,H,W,2] (NULL for nearest), g_uv_da [N,H,W,4] and
+ * g_mip_level_bias [N,H,W] (linear-mipmap-linear only, NULL when the input is absent) are fully
+ * written.  pull_mip_grads != 0 folds the level gradients into g_tex afterwards (the internal mip
+ * chain, torch_texture.cpp:679-687); custom stacks keep their own gradients. */
+int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_host, int L,
+                      const float* uv, const float* uv_da, const float* mip_level_bias, const float* dy,
+                      int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
+                      int filter_mode, int boundary_mode, int pull_mip_grads,
+                      float* g_tex, float* const* g_mip_ptrs_host,
+                      float* g_uv, float* g_uv_da, float* g_mip_level_bias, nvdrStream_t stream);
+
+/* ---- antialias ------------------------------------------------------------------
+ * Replaces antialias_construct_topology_hash / antialias_fwd / antialias_grad
+ * (torch_bindings.cpp:68-70; csrc/torch/torch_antialias.cpp:25-241). */
+
+size_t nvdr_antialias_hash_bytes(int T);                 /* torch_antialias.cpp:43-49 sizing */
+size_t nvdr_antialias_work_bytes(int N, int H, int W);   /* torch_antialias.cpp:123: (P*8+4) floats */
+
+/* Fills `hash` (cleared by the call) with the edge -> opposite-vertex table of `tri` [T,3]. */
+int nvdr_antialias_construct_topology_hash(const int32_t* tri, int T, void* hash, size_t hash_bytes,
+                                           nvdrStream_t stream);
+
+/* color / out [N,H,W,C]; rast [N,H,W,4]; pos [N,V,4] (instance_mode) or [V,4].  `work` receives
+ * the work items that the gradient pass replays; out is fully written (copy of color + blend). */
+int nvdr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                       const void* hash, size_t hash_bytes,
+                       int instance_mode, int N, int V, int T, int H, int W, int C,
+                       float* out, void* work, size_t work_bytes, nvdrStream_t stream);
+
+/* g_color [N,H,W,C] is fully written (copy of dy + corrections); g_pos (shape of pos) must be
+ * zero-filled by the caller (torch_antialias.cpp:219). */
+int nvdr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                        const float* dy, const void* work, size_t work_bytes,
+                        int instance_mode, int N, int V, int T, int H, int W, int C,
+                        float* g_color, float* g_pos, nvdrStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

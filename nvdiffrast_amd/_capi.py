@@ -12,6 +12,9 @@ _lib = None
 
 c_void_p, c_int, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 _i32p = ctypes.POINTER(ctypes.c_int32)
+_intp = ctypes.POINTER(ctypes.c_int)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
 SIGNATURES = {
@@ -31,7 +34,30 @@ SIGNATURES = {
     "nvdr_interpolate_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nvdr_texture_mip_info": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _intp, _intp, _i64p, _i64p]),
+    "nvdr_texture_construct_mip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nvdr_texture_fwd": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nvdr_texture_grad": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_void_p, _vpp, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nvdr_antialias_hash_bytes": (c_size_t, [c_int]),
+    "nvdr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "nvdr_antialias_construct_topology_hash": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "nvdr_antialias_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nvdr_antialias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (ctypes void*[]) for a list of torch tensors; (array, n)."""
+    n = len(tensors)
+    arr = (c_void_p * max(n, 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr, n
 
 
 def lib_path():

@@ -1,0 +1,437 @@
+// antialias.hip -- silhouette antialiasing forward / backward for gfx950.
+//
+// Replaces csrc/common/antialias.cu + csrc/torch/torch_antialias.cpp behind the C ABI.
+//
+//  k_aa_mesh           one lane per triangle: edge -> opposite-vertex table (open addressing,
+//                      64-bit CAS on the key, then CAS into the first free of two value slots;
+//                      antialias.cu:82-96,139-160).  The table layout is private to this library
+//                      (the reference's TopologyHashWrapper is opaque, torch_types.h:37-45).
+//  k_aa_discontinuity  one lane per pixel in scan-line order; a wave counts its candidate
+//                      (pixel, right|down) pairs with two ballots and reserves their slots in the
+//                      work buffer with ONE atomic per wave (the reference: one per 32x8 CTA
+//                      through shared memory, :197-209).
+//  k_aa_analysis       one lane per work item, grid-stride (item count lives on the device):
+//                      silhouette test, edge crossing, blend with hardware f32 atomics (:236-379).
+//  k_aa_grad           one lane per work item with alpha != 0 (:406-554).
+#include "nvdr_device.hpp"
+#include "nvdr_host.hpp"
+
+namespace nvdr {
+
+constexpr float kF32Max = 3.402823466e+38f;
+
+struct AAParams {
+    const float* color; const float* rast; const int* tri; const float* pos;
+    float* output; const float* dy; float* gradColor; float* gradPos;
+    int4* work; uint4* hash;
+    unsigned hashMask;
+    int numTriangles, numVertices, width, height, n, channels, instance;
+    float xh, yh;
+};
+
+__device__ __forceinline__ bool same_sign(float a, float b) { return (__float_as_int(a) ^ __float_as_int(b)) >= 0; }
+__device__ __forceinline__ bool rational_gt(float n0, float n1, float d0, float d1)
+{
+#pragma clang fp contract(off)
+    return (n0 * d1 > n1 * d0) == same_sign(d0, d1);
+}
+__device__ __forceinline__ int max_idx3(float n0, float n1, float n2, float d0, float d1, float d2)
+{
+    const bool g10 = rational_gt(n1, n0, d1, d0);
+    const bool g20 = rational_gt(n2, n0, d2, d0);
+    const bool g21 = rational_gt(n2, n1, d2, d1);
+    if (g20 && g21) return 2;
+    if (g10) return 1;
+    return 0;
+}
+
+// ---- topology table ------------------------------------------------------------------------
+
+__device__ __forceinline__ void hash_start(unsigned long long key, unsigned mask, unsigned& idx, unsigned& skip)
+{
+    unsigned long long k = key;
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    idx = (unsigned)k & mask;
+    skip = ((unsigned)(k >> 32) & mask) | 1u;          // odd skip visits every slot of a power-of-two table
+}
+
+__device__ __forceinline__ unsigned long long edge_key(int va, int vb)
+{
+    const unsigned long long v0 = (unsigned)min(va, vb) + 1u, v1 = (unsigned)max(va, vb) + 1u;
+    return v0 | (v1 << 32);
+}
+
+__device__ void hash_insert_vertex(const AAParams& p, int va, int vb, int vn)
+{
+    if (va == vb) return;
+    const unsigned long long key = edge_key(va, vb);
+    unsigned idx, skip;
+    hash_start(key, p.hashMask, idx, skip);
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long*)&p.hash[idx], 0ull, key);
+        if (prev == 0ull || prev == key) break;
+        idx = (idx + skip) & p.hashMask;
+    }
+    int* q = (int*)&p.hash[idx];
+    const int v = vn + 1;
+    const int a = atomicCAS(q + 2, 0, v);
+    if (a != 0 && a != v) atomicCAS(q + 3, 0, v);
+}
+
+__device__ __forceinline__ int hash_find_vertex(const AAParams& p, int va, int vb, int vr)
+{
+    if (va == vb) return -1;
+    const unsigned long long key = edge_key(va, vb);
+    unsigned idx, skip;
+    hash_start(key, p.hashMask, idx, skip);
+    for (;;) {
+        const uint4 e = p.hash[idx];
+        const unsigned long long k = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+        if (k == key || k == 0ull) {
+            const int x = (int)e.z - 1, y = (int)e.w - 1;
+            if (k == 0ull) return -1;
+            if (x == vr) return y;
+            if (y == vr) return x;
+            return -1;
+        }
+        idx = (idx + skip) & p.hashMask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_aa_mesh(const AAParams p)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.numTriangles) return;
+    const int v0 = p.tri[idx * 3 + 0], v1 = p.tri[idx * 3 + 1], v2 = p.tri[idx * 3 + 2];
+    if (v0 < 0 || v1 < 0 || v2 < 0) return;                // numVertices is unknown here (torch_antialias.cpp:40)
+    if (v0 == v1 || v1 == v2 || v2 == v0) return;
+    hash_insert_vertex(p, v1, v2, v0);
+    hash_insert_vertex(p, v2, v0, v1);
+    hash_insert_vertex(p, v0, v1, v2);
+}
+
+// ---- discontinuity finder (antialias.cu:165-214) ------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p)
+{
+    const size_t total = (size_t)p.width * p.height * p.n;
+    const size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool c1 = false, c2 = false;
+    int px = 0, py = 0, pz = 0;
+    if (pidx < total) {
+        px = (int)(pidx % p.width);
+        const size_t t = pidx / p.width;
+        py = (int)(t % p.height);
+        pz = (int)(t / p.height);
+        const float tri0 = p.rast[pidx * 4 + 3];            // compared as floats, like the reference
+        if (px < p.width - 1)  c1 = p.rast[(pidx + 1) * 4 + 3] != tri0;
+        if (py < p.height - 1) c2 = p.rast[(pidx + p.width) * 4 + 3] != tri0;
+    }
+    const uint64_t m1 = __ballot(c1), m2 = __ballot(c2);
+    const int n1 = __popcll(m1), n2 = __popcll(m2);
+    if (n1 + n2 == 0) return;
+    int base = 0;
+    if (lane_id() == 0) base = atomicAdd(&p.work[0].x, n1 + n2);
+    base = __builtin_amdgcn_readfirstlane(base) + 1;         // slot 0 holds the counters
+    if (c1) p.work[base + mask_rank(m1)] = make_int4(px, py, pz << 16, 0);
+    if (c2) p.work[base + n1 + mask_rank(m2)] = make_int4(px, py, (pz << 16) + (1 << 2), 0);
+}
+
+// ---- analysis + blend (antialias.cu:219-382) ------------------------------------------------------
+
+__device__ __forceinline__ void swapf(float& a, float& b) { const float t = a; a = b; b = t; }
+
+__global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
+{
+#pragma clang fp contract(off)
+    const int workCount = p.work[0].x;
+    for (int item_idx = blockIdx.x * 256 + threadIdx.x; item_idx < workCount; item_idx += gridDim.x * 256) {
+        int4* pItem = p.work + item_idx + 1;
+        const int4 item = *pItem;
+        int px = item.x, py = item.y;
+        const int pz = (int)(((unsigned)item.z) >> 16);
+        const int d = (item.z >> 2) & 1;
+
+        const size_t pixel0 = (size_t)px + (size_t)p.width * (py + (size_t)p.height * pz);
+        const size_t pixel1 = pixel0 + (d ? (size_t)p.width : 1);
+        const float2 zt0 = ((const float2*)p.rast)[pixel0 * 2 + 1];
+        const float2 zt1 = ((const float2*)p.rast)[pixel1 * 2 + 1];
+        const int tri0 = float_to_triidx(zt0.y) - 1;
+        const int tri1 = float_to_triidx(zt1.y) - 1;
+
+        int tri = (tri0 >= 0) ? tri0 : tri1;
+        if (tri0 >= 0 && tri1 >= 0) tri = (zt0.x < zt1.x) ? tri0 : tri1;
+        if (tri == tri1) { px += 1 - d; py += d; }
+        if (tri < 0 || tri >= p.numTriangles) continue;
+
+        int vi0 = p.tri[tri * 3 + 0], vi1 = p.tri[tri * 3 + 1], vi2 = p.tri[tri * 3 + 2];
+        if (vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices) continue;
+
+        int op0 = hash_find_vertex(p, vi2, vi1, vi0);
+        int op1 = hash_find_vertex(p, vi0, vi2, vi1);
+        int op2 = hash_find_vertex(p, vi1, vi0, vi2);
+        // A table built for another mesh may name vertices this one does not have.
+        if (op0 >= p.numVertices) op0 = -1;
+        if (op1 >= p.numVertices) op1 = -1;
+        if (op2 >= p.numVertices) op2 = -1;
+        const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)pz * p.numVertices : 0);
+        const float4 p0 = vb[vi0], p1 = vb[vi1], p2 = vb[vi2];
+        const float4 o0 = (op0 < 0) ? p0 : vb[op0];
+        const float4 o1 = (op1 < 0) ? p1 : vb[op1];
+        const float4 o2 = (op2 < 0) ? p2 : vb[op2];
+
+        const float w0 = 1.f / p0.w, w1 = 1.f / p1.w, w2 = 1.f / p2.w;
+        const float ow0 = 1.f / o0.w, ow1 = 1.f / o1.w, ow2 = 1.f / o2.w;
+        const float fx = (float)px + .5f - p.xh;
+        const float fy = (float)py + .5f - p.yh;
+        float x0 = p0.x * w0 * p.xh - fx, y0 = p0.y * w0 * p.yh - fy;
+        float x1 = p1.x * w1 * p.xh - fx, y1 = p1.y * w1 * p.yh - fy;
+        float x2 = p2.x * w2 * p.xh - fx, y2 = p2.y * w2 * p.yh - fy;
+        const float ox0 = o0.x * ow0 * p.xh - fx, oy0 = o0.y * ow0 * p.yh - fy;
+        const float ox1 = o1.x * ow1 * p.xh - fx, oy1 = o1.y * ow1 * p.yh - fy;
+        const float ox2 = o2.x * ow2 * p.xh - fx, oy2 = o2.y * ow2 * p.yh - fy;
+
+        const float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+        const float a0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
+        const float a1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
+        const float a2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
+        if (!(same_sign(a0, bb) || same_sign(a1, bb) || same_sign(a2, bb))) continue;
+
+        if (d) { swapf(x0, y0); swapf(x1, y1); swapf(x2, y2); }
+        const float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
+        float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
+
+        float dc = -kF32Max;
+        const float ds = (tri == tri0) ? 1.f : -1.f;
+        float d0 = ds * (x1 * dy0 - y1 * dx0);
+        float d1 = ds * (x2 * dy1 - y2 * dx1);
+        float d2 = ds * (x0 * dy2 - y0 * dx2);
+        if (same_sign(y1, y2)) { d0 = -kF32Max; dy0 = 1.f; }
+        if (same_sign(y2, y0)) { d1 = -kF32Max; dy1 = 1.f; }
+        if (same_sign(y0, y1)) { d2 = -kF32Max; dy2 = 1.f; }
+
+        const int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
+        if (di == 0 && same_sign(a0, bb) && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
+        if (di == 1 && same_sign(a1, bb) && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
+        if (di == 2 && same_sign(a2, bb) && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
+        const float eps = .0625f;
+
+        if (dc > -eps && dc < 1.f + eps) {
+            dc = fminf(fmaxf(dc, 0.f), 1.f);
+            const float alpha = ds * (.5f - dc);
+            const float* pColor0 = p.color + pixel0 * p.channels;
+            const float* pColor1 = p.color + pixel1 * p.channels;
+            float* pOutput = p.output + (alpha > 0.f ? pixel0 : pixel1) * p.channels;
+            for (int i = 0; i < p.channels; i++) atomic_add_f32(&pOutput[i], alpha * (pColor1[i] - pColor0[i]));
+
+            unsigned flags = (unsigned)pz << 16;
+            flags |= (unsigned)di;
+            flags |= (unsigned)d << 2;
+            flags |= ((unsigned)__float_as_int(ds) >> 31) << 3;
+            ((int2*)pItem)[1] = make_int2((int)flags, __float_as_int(alpha));
+        }
+    }
+}
+
+// ---- gradients (antialias.cu:387-556) ---------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_aa_grad(const AAParams p)
+{
+#pragma clang fp contract(off)
+    const int workCount = p.work[0].x;
+    for (int item_idx = blockIdx.x * 256 + threadIdx.x; item_idx < workCount; item_idx += gridDim.x * 256) {
+        const int4 item = p.work[item_idx + 1];
+        if (item.w == 0) continue;                                    // bits of alpha: no effect
+
+        int px = item.x, py = item.y;
+        const int pz = (int)(((unsigned)item.z) >> 16);
+        const int d = (item.z >> 2) & 1;
+        const float alpha = __int_as_float(item.w);
+        const int tri1 = (item.z >> 3) & 1;
+        const int di = item.z & 3;
+        const size_t pixel0 = (size_t)px + (size_t)p.width * (py + (size_t)p.height * pz);
+        const size_t pixel1 = pixel0 + (d ? (size_t)p.width : 1);
+        const int tri = float_to_triidx(p.rast[((tri1 ? pixel1 : pixel0) << 2) + 3]) - 1;
+        if (tri1) { px += 1 - d; py += d; }
+        if (tri < 0 || tri >= p.numTriangles) continue;
+
+        float* pGrad0 = p.gradColor + pixel0 * p.channels;
+        float* pGrad1 = p.gradColor + pixel1 * p.channels;
+        const float* pDy = p.dy + (alpha > 0.f ? pixel0 : pixel1) * p.channels;
+        const float* pColor0 = p.color + pixel0 * p.channels;
+        const float* pColor1 = p.color + pixel1 * p.channels;
+
+        float dd = 0.f;
+        for (int i = 0; i < p.channels; i++) {
+            const float dy = pDy[i];
+            if (dy != 0.f) {
+                dd += dy * (pColor1[i] - pColor0[i]);
+                const float v = alpha * dy;
+                atomic_add_f32(&pGrad0[i], -v);
+                atomic_add_f32(&pGrad1[i], v);
+            }
+        }
+        if (dd == 0.f) continue;
+
+        const int i1 = (di < 2) ? (di + 1) : 0;
+        const int i2 = (i1 < 2) ? (i1 + 1) : 0;
+        int vi1 = p.tri[3 * tri + i1], vi2 = p.tri[3 * tri + i2];
+        if (vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices) continue;
+        if (p.instance) { vi1 += pz * p.numVertices; vi2 += pz * p.numVertices; }
+
+        float4 p1 = ((const float4*)p.pos)[vi1];
+        float4 p2 = ((const float4*)p.pos)[vi2];
+        float pxh = p.xh, pyh = p.yh;
+        float fx = (float)px + .5f - pxh;
+        float fy = (float)py + .5f - pyh;
+        if (d) { swapf(p1.x, p1.y); swapf(p2.x, p2.y); swapf(pxh, pyh); swapf(fx, fy); }
+
+        const float w1 = 1.f / p1.w, w2 = 1.f / p2.w;
+        const float x1 = p1.x * w1 * pxh - fx, y1 = p1.y * w1 * pyh - fy;
+        const float x2 = p2.x * w2 * pxh - fx, y2 = p2.y * w2 * pyh - fy;
+        const float dx = x2 - x1, dy = y2 - y1;
+        const float db = x1 * dy - y1 * dx;
+        const float ep = copysignf(1e-3f, dy);
+        const float iy = 1.f / (dy + ep);
+        const float dby = db * iy;
+        const float iw1 = -w1 * iy * dd, iw2 = w2 * iy * dd;
+        float gp1x = iw1 * pxh * y2, gp2x = iw2 * pxh * y1;
+        float gp1y = iw1 * pyh * (dby - x2), gp2y = iw2 * pyh * (dby - x1);
+        float gp1w = -(p1.x * gp1x + p1.y * gp1y) * w1;
+        float gp2w = -(p2.x * gp2x + p2.y * gp2y) * w2;
+        if (d) { swapf(gp1x, gp1y); swapf(gp2x, gp2y); }
+        if (fabsf(alpha) >= 0.5f) { gp1x = gp1y = gp1w = 0.f; gp2x = gp2y = gp2w = 0.f; }
+
+        float* q1 = p.gradPos + 4 * (size_t)vi1;
+        float* q2 = p.gradPos + 4 * (size_t)vi2;
+        atomic_add_f32(q1 + 0, gp1x); atomic_add_f32(q1 + 1, gp1y); atomic_add_f32(q1 + 3, gp1w);
+        atomic_add_f32(q2 + 0, gp2x); atomic_add_f32(q2 + 1, gp2y); atomic_add_f32(q2 + 3, gp2w);
+    }
+}
+
+static int alloc_triangles(int T) { int a = 64; while (a < T) a <<= 1; return a; }           // torch_antialias.cpp:43-45
+static int hash_elems_per_tri(int alloc) { return alloc >= (2 << 25) ? 4 : 8; }              // antialias.h:19
+
+static int fill_aa(AAParams& p, const char* who, const float* color, const float* rast, const float* pos, const int32_t* tri,
+                   int instance_mode, int N, int V, int T, int H, int W, int C)
+{
+    NVDR_REQUIRE(color && rast && pos && tri, "%s: null pointer", who);
+    NVDR_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0, "color must have shape[>0, >0, >0, >0]");
+    NVDR_REQUIRE(T > 0, "tri must have shape [>0, 3]");
+    NVDR_REQUIRE(V > 0, "pos must have shape [>0, >0, 4] or [>0, 4]");
+    NVDR_REQUIRE(N < 65536, "%s: minibatch too large for the work-item encoding (16 bits)", who);
+    NVDR_REQUIRE((long long)N * H * W * 2 + 1 < (1ll << 31), "%s: too many pixels for 32-bit work-item indices", who);
+    NVDR_REQUIRE(!((uintptr_t)pos & 15), "pos input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)rast & 7), "raster_out input tensor not aligned to float2");
+    p = AAParams{};
+    p.color = color; p.rast = rast; p.pos = pos; p.tri = tri;
+    p.numTriangles = T; p.numVertices = V; p.width = W; p.height = H; p.n = N; p.channels = C;
+    p.instance = instance_mode ? 1 : 0;
+    p.xh = .5f * (float)W; p.yh = .5f * (float)H;
+    return NVDR_OK;
+}
+
+static int item_grid(long long max_items)
+{
+    long long blocks = (max_items + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;                   // grid-stride beyond 8 workgroups per CU
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace nvdr
+
+using namespace nvdr;
+
+extern "C" size_t nvdr_antialias_hash_bytes(int T)
+{
+    if (T <= 0) return 0;
+    const int alloc = alloc_triangles(T);
+    return (size_t)alloc * hash_elems_per_tri(alloc) * 16;
+}
+
+extern "C" size_t nvdr_antialias_work_bytes(int N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return ((size_t)N * H * W * 8 + 4) * 4;                   // torch_antialias.cpp:123: two 16-byte items per pixel + counters
+}
+
+extern "C" int nvdr_antialias_construct_topology_hash(const int32_t* tri, int T, void* hash, size_t hash_bytes, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_REQUIRE(tri && hash, "antialias_construct_topology_hash: null pointer");
+    NVDR_REQUIRE(T > 0, "tri must have shape [>0, 3]");
+    NVDR_REQUIRE(!((uintptr_t)hash & 15), "ev_hash internal tensor not aligned to int4");
+    const size_t need = nvdr_antialias_hash_bytes(T);
+    if (hash_bytes < need) { set_error("antialias_construct_topology_hash: hash buffer too small (%zu < %zu)", hash_bytes, need); return NVDR_ERR_SCRATCH; }
+    AAParams p{};
+    p.tri = tri; p.numTriangles = T; p.numVertices = 0x7fffffff;
+    p.hash = (uint4*)hash;
+    p.hashMask = (unsigned)(need / 16 - 1);
+    NVDR_HIP_CHECK(hipMemsetAsync(hash, 0, need, stream));
+    {
+        ProfileScope ps("aa_mesh", stream);
+        hipLaunchKernelGGL(k_aa_mesh, dim3((T + 255) / 256), dim3(256), 0, stream, p);
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}
+
+extern "C" int nvdr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                                  const void* hash, size_t hash_bytes,
+                                  int instance_mode, int N, int V, int T, int H, int W, int C,
+                                  float* out, void* work, size_t work_bytes, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    AAParams p;
+    int rc = fill_aa(p, "antialias_fwd", color, rast, pos, tri, instance_mode, N, V, T, H, W, C);
+    if (rc) return rc;
+    NVDR_REQUIRE(hash && out && work, "antialias_fwd: null pointer");
+    NVDR_REQUIRE(!((uintptr_t)work & 15), "work_buffer internal tensor not aligned to int4");
+    NVDR_REQUIRE(!((uintptr_t)hash & 15), "topology_hash internal tensor not aligned to int4");
+    const size_t need_hash = nvdr_antialias_hash_bytes(T);
+    if (hash_bytes < need_hash) { set_error("antialias_fwd: topology hash was built for fewer triangles (%zu < %zu bytes)", hash_bytes, need_hash); return NVDR_ERR_ARG; }
+    if (work_bytes < nvdr_antialias_work_bytes(N, H, W)) { set_error("antialias_fwd: work buffer too small"); return NVDR_ERR_SCRATCH; }
+    p.hash = (uint4*)hash;
+    p.hashMask = (unsigned)(hash_bytes / 16 - 1);
+    NVDR_REQUIRE(((hash_bytes / 16) & (hash_bytes / 16 - 1)) == 0, "antialias_fwd: topology hash size is not a power of two");
+    p.output = out; p.work = (int4*)work;
+    const size_t P = (size_t)N * H * W;
+    // out = color (torch_antialias.cpp:122 clones), counters = 0.
+    NVDR_HIP_CHECK(hipMemcpyAsync(out, color, P * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    NVDR_HIP_CHECK(hipMemsetAsync(work, 0, 16, stream));
+    {
+        ProfileScope ps("aa_discontinuity", stream);
+        hipLaunchKernelGGL(k_aa_discontinuity, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, p);
+    }
+    NVDR_LAUNCH_CHECK();
+    {
+        ProfileScope ps("aa_analysis", stream);
+        hipLaunchKernelGGL(k_aa_analysis, dim3(item_grid((long long)P * 2)), dim3(256), 0, stream, p);
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}
+
+extern "C" int nvdr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                                   const float* dy, const void* work, size_t work_bytes,
+                                   int instance_mode, int N, int V, int T, int H, int W, int C,
+                                   float* g_color, float* g_pos, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    AAParams p;
+    int rc = fill_aa(p, "antialias_grad", color, rast, pos, tri, instance_mode, N, V, T, H, W, C);
+    if (rc) return rc;
+    NVDR_REQUIRE(dy && work && g_color && g_pos, "antialias_grad: null pointer");
+    NVDR_REQUIRE(!((uintptr_t)work & 15), "work_buffer internal tensor not aligned to int4");
+    if (work_bytes < nvdr_antialias_work_bytes(N, H, W)) { set_error("antialias_grad: work buffer too small"); return NVDR_ERR_SCRATCH; }
+    p.dy = dy; p.work = (int4*)work; p.gradColor = g_color; p.gradPos = g_pos;
+    const size_t P = (size_t)N * H * W;
+    // g_color = dy (torch_antialias.cpp:218 clones); g_pos is zero-filled by the caller.
+    NVDR_HIP_CHECK(hipMemcpyAsync(g_color, dy, P * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    {
+        ProfileScope ps("aa_grad", stream);
+        hipLaunchKernelGGL(k_aa_grad, dim3(item_grid((long long)P * 2)), dim3(256), 0, stream, p);
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}

@@ -1,0 +1,577 @@
+// texture.hip -- texture sampling forward / backward, mip construction for gfx950.
+//
+// Replaces csrc/common/texture_kernel.cu + csrc/common/texture.cpp + csrc/torch/torch_texture.cpp
+// behind the C ABI (2D textures; cube maps are rejected with a message).
+//
+//  k_mip_build   one lane per output texel, 2x2 box filter (texture_kernel.cu:644-699).
+//  k_tex_fwd     one lane per pixel, a wave = one 8x8 pixel tile so that the 4..8 texel taps of
+//                a wave land in a compact texture footprint (L1/L2 hits); uv / uv_da / out are
+//                read and written as whole float2 / float4 per lane.  Tiles are handed to the
+//                XCDs in contiguous chunks so neighbouring tiles share an L2.
+//  k_tex_grad    same mapping; texel-weight scatter with hardware f32 atomics, uv / uv_da /
+//                bias gradients written per pixel (texture_kernel.cu:905-1140).
+//  k_mip_grad    one lane per base texel pulls its ancestors' gradients (:843-895).
+#include "nvdr_device.hpp"
+#include "nvdr_host.hpp"
+
+namespace nvdr {
+
+constexpr int kTexMaxLevels = 17;                 // texture.h:24 TEX_MAX_MIP_LEVEL (16) + base level
+enum { TEX_NEAREST = 0, TEX_LINEAR = 1, TEX_LMN = 2, TEX_LML = 3 };          // ops.py:415
+enum { TEX_B_CUBE = 0, TEX_B_WRAP = 1, TEX_B_CLAMP = 2, TEX_B_ZERO = 3 };    // ops.py:417
+
+struct TexParams {
+    const float* tex[kTexMaxLevels];
+    float*       gradTex[kTexMaxLevels];
+    const float* uv; const float* uvDA; const float* bias; const float* dy;
+    float* out; float* gradUV; float* gradUVDA; float* gradBias;
+    int boundary, channels, imgW, imgH, n, texW, texH, texDepth, levelMax;
+    int tilesX, tilesY;
+};
+
+__device__ __forceinline__ int level_dim(int d, int level) { int v = d >> level; return v > 1 ? v : 1; }
+
+// texture_kernel.cu:322-366
+__device__ __forceinline__ long long tex_index_nearest(const TexParams& p, float u, float v, int tz)
+{
+#pragma clang fp contract(off)
+    const int w = p.texW, h = p.texH;
+    if (p.boundary == TEX_B_WRAP) { u = u - floorf(u); v = v - floorf(v); }
+    u = u * (float)w;
+    v = v * (float)h;
+    int iu = __float2int_rd(u), iv = __float2int_rd(v);
+    if (p.boundary == TEX_B_ZERO && (iu < 0 || iu >= w || iv < 0 || iv >= h)) return -1;
+    iu = min(max(iu, 0), w - 1);
+    iv = min(max(iv, 0), h - 1);
+    return (long long)iu + (long long)w * (iv + (long long)tz * h);
+}
+
+struct Quad { long long tc[4]; float fu, fv; };          // texel indices x0y0, x1y0, x0y1, x1y1 (or -1) and weights
+
+// texture_kernel.cu:368-472.  The one explicit fma is where the reference's compiler contracts.
+__device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, float v, int tz, int level)
+{
+#pragma clang fp contract(off)
+    const int w = level_dim(p.texW, level), h = level_dim(p.texH, level);
+    bool clampU = false, clampV = false;
+    if (p.boundary == TEX_B_WRAP) { u = u - floorf(u); v = v - floorf(v); }
+    u = __fmaf_rn(u, (float)w, -0.5f);
+    v = __fmaf_rn(v, (float)h, -0.5f);
+    if (p.boundary == TEX_B_CLAMP) {
+        u = fminf(fmaxf(u, 0.f), (float)w - 1.f);
+        v = fminf(fmaxf(v, 0.f), (float)h - 1.f);
+        clampU = (u == 0.f || u == (float)w - 1.f);
+        clampV = (v == 0.f || v == (float)h - 1.f);
+    }
+    int iu0 = __float2int_rd(u), iv0 = __float2int_rd(v);
+    int iu1 = iu0 + (clampU ? 0 : 1), iv1 = iv0 + (clampV ? 0 : 1);
+    Quad q;
+    q.fu = u - (float)iu0;
+    q.fv = v - (float)iv0;
+    if (p.boundary == TEX_B_WRAP) {
+        if (iu0 < 0) iu0 += w;
+        if (iv0 < 0) iv0 += h;
+        if (iu1 >= w) iu1 -= w;
+        if (iv1 >= h) iv1 -= h;
+    }
+    const long long base = (long long)tz * w * h;
+    q.tc[0] = base + iu0 + (long long)w * iv0;
+    q.tc[1] = base + iu1 + (long long)w * iv0;
+    q.tc[2] = base + iu0 + (long long)w * iv1;
+    q.tc[3] = base + iu1 + (long long)w * iv1;
+    if (p.boundary == TEX_B_ZERO) {
+        const bool u0o = (iu0 < 0 || iu0 >= w), u1o = (iu1 < 0 || iu1 >= w);
+        const bool v0o = (iv0 < 0 || iv0 >= h), v1o = (iv1 < 0 || iv1 >= h);
+        if (u0o || v0o) q.tc[0] = -1;
+        if (u1o || v0o) q.tc[1] = -1;
+        if (u0o || v1o) q.tc[2] = -1;
+        if (u1o || v1o) q.tc[3] = -1;
+    }
+    return q;
+}
+
+__device__ __forceinline__ bool finite4(float4 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z) && isfinite(a.w); }
+
+// texture_kernel.cu:477-585
+template <int FILTER, bool BIAS_ONLY>
+__device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, int& level0, int& level1, float& flevel, float4* dw)
+{
+#pragma clang fp contract(off)
+    level0 = 0; level1 = 0; flevel = 0.f;
+    if (FILTER == TEX_NEAREST || FILTER == TEX_LINEAR) return;
+    if (!BIAS_ONLY) {
+        const float4 d = ((const float4*)p.uvDA)[pidx];
+        const float uscl = (float)p.texW, vscl = (float)p.texH;
+        const float dsdx = d.x * uscl, dsdy = d.y * uscl, dtdx = d.z * vscl, dtdy = d.w * vscl;
+        const float A = dsdx * dsdx + dtdx * dtdx;
+        const float B = dsdy * dsdy + dtdy * dtdy;
+        const float C = dsdx * dsdy + dtdx * dtdy;
+        const float l2b = 0.5f * (A + B);
+        const float l2n = 0.25f * (A - B) * (A - B) + C * C;
+        const float l2a = sqrtf(l2n);
+        const float lenMajorSqr = l2b + l2a;
+        if (dw && FILTER == TEX_LML) {
+            const float k = 0.72134752f / (l2n + l2a * l2b);                  // 0.5 / ln 2
+            const float AB = k * .5f * (A - B);
+            const float Cw = k * C;
+            const float l2aw = k * l2a;
+            const float4 g = make_float4(uscl * (dsdx * (l2aw + AB) + dsdy * Cw), uscl * (dsdy * (l2aw - AB) + dsdx * Cw),
+                                         vscl * (dtdx * (l2aw + AB) + dtdy * Cw), vscl * (dtdy * (l2aw - AB) + dtdx * Cw));
+            *dw = finite4(g) ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        flevel = .5f * log2f(lenMajorSqr);                                    // inf/NaN are fixed by the clamp
+    }
+    if (p.bias) flevel += p.bias[pidx];
+    flevel = fminf(fmaxf(flevel, 0.f), (float)p.levelMax);
+    level0 = __float2int_rd(flevel);
+    if (FILTER == TEX_LML && flevel > 0.f) {
+        level1 = min(level0 + 1, p.levelMax);
+        flevel -= (float)level0;
+    }
+}
+
+__device__ __forceinline__ float lerp1(float a, float b, float c) { return a + c * (b - a); }
+__device__ __forceinline__ float bilerp1(float a, float b, float c, float d, float fu, float fv) { return lerp1(lerp1(a, b, fu), lerp1(c, d, fu), fv); }
+
+// A texel's C_CT channels as one vector load when the channel count allows it.
+template <int C_CT> struct TexelVec { float v[C_CT > 0 ? C_CT : 1]; };
+
+template <int C_CT>
+__device__ __forceinline__ void load_texel(float* dst, const float* base, long long tc, int C)
+{
+    if (tc < 0) { for (int c = 0; c < (C_CT > 0 ? C_CT : C); c++) dst[c] = 0.f; return; }
+    const float* s = base + tc * (C_CT > 0 ? C_CT : C);
+    if (C_CT == 4) { const float4 t = *(const float4*)s; dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w; }
+    else if (C_CT == 2) { const float2 t = *(const float2*)s; dst[0] = t.x; dst[1] = t.y; }
+    else { for (int c = 0; c < (C_CT > 0 ? C_CT : C); c++) dst[c] = s[c]; }
+}
+
+// Pixel of this lane: waves own 8x8 tiles, tiles are dealt to XCDs in contiguous chunks.
+__device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, int& pz)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long tilesPerImage = (long long)p.tilesX * p.tilesY;
+    const long long totalGroups = (tilesPerImage * p.n + 3) >> 2;            // 4 tiles (waves) per workgroup
+    const long long perXcd = (totalGroups + 7) >> 3;
+    const long long j = blockIdx.x >> 3;
+    const long long group = (long long)(blockIdx.x & 7) * perXcd + j;
+    if (j >= perXcd || group >= totalGroups) return false;
+    const long long tile = group * 4 + wave;
+    if (tile >= tilesPerImage * p.n) return false;
+    pz = (int)(tile / tilesPerImage);
+    const int rem = (int)(tile - (long long)pz * tilesPerImage);
+    const int ty = rem / p.tilesX, tx = rem - ty * p.tilesX;
+    px = tx * 8 + (lane & 7);
+    py = ty * 8 + (lane >> 3);
+    return px < p.imgW && py < p.imgH;
+}
+
+// ---- forward (texture_kernel.cu:709-800) ---------------------------------------------------
+
+template <int FILTER, bool BIAS_ONLY, int C_CT>
+__global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
+{
+    int px, py, pz;
+    if (!tex_pixel(p, px, py, pz)) return;
+    constexpr int CMAX = C_CT > 0 ? C_CT : 1;
+    const int C = C_CT > 0 ? C_CT : p.channels;
+    const int tz = (p.texDepth == 1) ? 0 : pz;
+    const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
+    const float2 uv = ((const float2*)p.uv)[pidx];
+    float* pOut = p.out + pidx * C;
+
+    if (FILTER == TEX_NEAREST) {
+        const long long tc = tex_index_nearest(p, uv.x, uv.y, tz);
+        if (C_CT > 0) {
+            float t[CMAX];
+            load_texel<C_CT>(t, p.tex[0], tc, C);
+            if (C_CT == 4) *(float4*)pOut = make_float4(t[0], t[1], t[2], t[3 % CMAX]);
+            else if (C_CT == 2) *(float2*)pOut = make_float2(t[0], t[1 % CMAX]);
+            else for (int c = 0; c < C_CT; c++) pOut[c] = t[c];
+        } else {
+            for (int c = 0; c < C; c++) pOut[c] = tc >= 0 ? p.tex[0][tc * C + c] : 0.f;
+        }
+        return;
+    }
+
+    int level0, level1; float flevel;
+    tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, nullptr);
+    const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
+    const float* pIn0 = p.tex[level0];
+    const bool second = (FILTER == TEX_LML) && flevel > 0.f;
+    Quad q1 = q0;
+    const float* pIn1 = pIn0;
+    if (second) { q1 = tex_index_linear(p, uv.x, uv.y, tz, level1); pIn1 = p.tex[level1]; }
+
+    if (C_CT > 0) {
+        float a00[CMAX], a10[CMAX], a01[CMAX], a11[CMAX], r[CMAX];
+        load_texel<C_CT>(a00, pIn0, q0.tc[0], C); load_texel<C_CT>(a10, pIn0, q0.tc[1], C);
+        load_texel<C_CT>(a01, pIn0, q0.tc[2], C); load_texel<C_CT>(a11, pIn0, q0.tc[3], C);
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) r[c] = bilerp1(a00[c], a10[c], a01[c], a11[c], q0.fu, q0.fv);
+        if (second) {
+            float b00[CMAX], b10[CMAX], b01[CMAX], b11[CMAX];
+            load_texel<C_CT>(b00, pIn1, q1.tc[0], C); load_texel<C_CT>(b10, pIn1, q1.tc[1], C);
+            load_texel<C_CT>(b01, pIn1, q1.tc[2], C); load_texel<C_CT>(b11, pIn1, q1.tc[3], C);
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) r[c] = lerp1(r[c], bilerp1(b00[c], b10[c], b01[c], b11[c], q1.fu, q1.fv), flevel);
+        }
+        if (C_CT == 4) *(float4*)pOut = make_float4(r[0], r[1 % CMAX], r[2 % CMAX], r[3 % CMAX]);
+        else if (C_CT == 2) *(float2*)pOut = make_float2(r[0], r[1 % CMAX]);
+        else for (int c = 0; c < CMAX; c++) pOut[c] = r[c];
+    } else {
+        for (int c = 0; c < C; c++) {
+            float a = bilerp1(q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f,
+                              q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f, q0.fu, q0.fv);
+            if (second) {
+                const float b = bilerp1(q1.tc[0] >= 0 ? pIn1[q1.tc[0] * C + c] : 0.f, q1.tc[1] >= 0 ? pIn1[q1.tc[1] * C + c] : 0.f,
+                                        q1.tc[2] >= 0 ? pIn1[q1.tc[2] * C + c] : 0.f, q1.tc[3] >= 0 ? pIn1[q1.tc[3] * C + c] : 0.f, q1.fu, q1.fv);
+                a = lerp1(a, b, flevel);
+            }
+            pOut[c] = a;
+        }
+    }
+}
+
+// ---- backward (texture_kernel.cu:905-1140) -------------------------------------------------
+
+template <int FILTER, bool BIAS_ONLY>
+__global__ __launch_bounds__(256) void k_tex_grad(const TexParams p)
+{
+    int px, py, pz;
+    if (!tex_pixel(p, px, py, pz)) return;
+    const int C = p.channels;
+    const int tz = (p.texDepth == 1) ? 0 : pz;
+    const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
+    const float* pDy = p.dy + pidx * C;
+
+    // All-zero upstream gradient: explicit zero stores, no scatter (:922-971).
+    uint32_t dmax = 0u;
+    for (int c = 0; c < C; c++) dmax |= (uint32_t)__float_as_int(pDy[c]);
+    if (__int_as_float((int)dmax) == 0.f) {
+        if (FILTER != TEX_NEAREST) ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
+        if (FILTER == TEX_LML) {
+            if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.gradBias) p.gradBias[pidx] = 0.f;
+        }
+        return;
+    }
+    const float2 uv = ((const float2*)p.uv)[pidx];
+
+    if (FILTER == TEX_NEAREST) {
+        const long long tc = tex_index_nearest(p, uv.x, uv.y, tz);
+        if (tc < 0) return;
+        float* pOut = p.gradTex[0] + tc * C;
+        for (int c = 0; c < C; c++) atomic_add_f32(pOut + c, pDy[c]);
+        return;
+    }
+
+    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+    int level0, level1; float flevel;
+    tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, &dw);
+
+    const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
+    const float* pIn0 = p.tex[level0];
+    float* pOut0 = p.gradTex[level0];
+    const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
+    const float tw0[4] = {w000, w010, w001, w011};
+    const float sclu0 = (float)level_dim(p.texW, level0), sclv0 = (float)level_dim(p.texH, level0);
+    float gu = 0.f, gv = 0.f;
+
+    if (FILTER == TEX_LINEAR || FILTER == TEX_LMN) {
+        for (int c = 0; c < C; c++) {
+            const float d = pDy[c];
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) atomic_add_f32(pOut0 + q0.tc[k] * C + c, tw0[k] * d);
+            const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
+            const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
+            const float ad = (a11 + a00 - a10 - a01);
+            gu += d * ((a10 - a00) + q0.fv * ad) * sclu0;
+            gv += d * ((a01 - a00) + q0.fu * ad) * sclv0;
+        }
+        ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+        return;
+    }
+
+    // Trilinear.
+    float df = 0.f;
+    const Quad q1 = tex_index_linear(p, uv.x, uv.y, tz, level1);
+    const float* pIn1 = p.tex[level1];
+    float* pOut1 = p.gradTex[level1];
+    const float w111 = q1.fu * q1.fv, w110 = q1.fu - w111, w101 = q1.fv - w111, w100 = 1.f - q1.fu - w101;
+    const float tw1[4] = {w100, w110, w101, w111};
+    const float sclu1 = (float)level_dim(p.texW, level1), sclv1 = (float)level_dim(p.texH, level1);
+    for (int c = 0; c < C; c++) {
+        const float d = pDy[c];
+        const float d0 = (1.f - flevel) * d;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) atomic_add_f32(pOut0 + q0.tc[k] * C + c, tw0[k] * d0);
+        const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
+        const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
+        const float ad = (a11 + a00 - a10 - a01);
+        gu += d0 * ((a10 - a00) + q0.fv * ad) * sclu0;
+        gv += d0 * ((a01 - a00) + q0.fu * ad) * sclv0;
+        if (flevel > 0.f) {
+            const float d1 = flevel * d;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (q1.tc[k] >= 0) atomic_add_f32(pOut1 + q1.tc[k] * C + c, tw1[k] * d1);
+            const float b00 = q1.tc[0] >= 0 ? pIn1[q1.tc[0] * C + c] : 0.f, b10 = q1.tc[1] >= 0 ? pIn1[q1.tc[1] * C + c] : 0.f;
+            const float b01 = q1.tc[2] >= 0 ? pIn1[q1.tc[2] * C + c] : 0.f, b11 = q1.tc[3] >= 0 ? pIn1[q1.tc[3] * C + c] : 0.f;
+            const float bd = (b11 + b00 - b10 - b01);
+            gu += d1 * ((b10 - b00) + q1.fv * bd) * sclu1;
+            gv += d1 * ((b01 - b00) + q1.fu * bd) * sclv1;
+            const float a = bilerp1(a00, a10, a01, a11, q0.fu, q0.fv);
+            const float b = bilerp1(b00, b10, b01, b11, q1.fu, q1.fv);
+            df += (b - a) * d;
+        }
+    }
+    ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+    if (p.gradBias) p.gradBias[pidx] = df;
+    if (!BIAS_ONLY && p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(dw.x * df, dw.y * df, dw.z * df, dw.w * df);
+}
+
+// ---- mip construction / mip gradient pull ------------------------------------------------------
+
+struct MipParams { const float* in; float* out; int wi, hi, wo, ho, depth, C; };
+
+__global__ __launch_bounds__(256) void k_mip_build(const MipParams p)
+{
+    const long long total = (long long)p.wo * p.ho * p.depth * p.C;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % p.C);
+    long long t = i / p.C;
+    const int x = (int)(t % p.wo); t /= p.wo;
+    const int y = (int)(t % p.ho);
+    const int z = (int)(t / p.ho);
+    const float* in = p.in;
+    if (p.wi == 1 || p.hi == 1) {                          // one extent already 1: average the two remaining texels
+        const long long i0 = (p.hi == 1) ? ((long long)z * p.hi * p.wi + 2ll * x) : ((long long)z * p.hi * p.wi + 2ll * y * p.wi);
+        const long long i1 = (p.hi == 1) ? i0 + 1 : i0 + p.wi;
+        p.out[i] = .5f * (in[i0 * p.C + c] + in[i1 * p.C + c]);
+    } else {
+        const long long i0 = ((long long)z * p.hi + 2ll * y) * p.wi + 2ll * x;
+        const float v0 = in[i0 * p.C + c], v1 = in[(i0 + 1) * p.C + c];
+        const float v2 = in[(i0 + p.wi) * p.C + c], v3 = in[(i0 + p.wi + 1) * p.C + c];
+        p.out[i] = .25f * (((v0 + v1) + v2) + v3);
+    }
+}
+
+struct MipGradParams { float* gradTex[kTexMaxLevels]; int texW, texH, depth, C, levelMax; };
+
+__global__ __launch_bounds__(256) void k_mip_grad(const MipGradParams p)
+{
+    const long long total = (long long)p.texW * p.texH * p.depth * p.C;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % p.C);
+    long long t = i / p.C;
+    int x = (int)(t % p.texW); t /= p.texW;
+    int y = (int)(t % p.texH);
+    const int z = (int)(t / p.texH);
+    float acc = 0.f, w = 1.f;
+    int pw = p.texW, ph = p.texH;
+    for (int level = 1; level <= p.levelMax; level++) {
+        if (pw > 1) w *= .5f;
+        if (ph > 1) w *= .5f;
+        pw = level_dim(p.texW, level); ph = level_dim(p.texH, level);
+        x >>= 1; y >>= 1;
+        acc += p.gradTex[level][(((long long)z * ph + y) * pw + x) * p.C + c] * w;
+    }
+    p.gradTex[0][i] += acc;
+}
+
+static int mip_info(int tex_n, int tex_h, int tex_w, int C, int cube, int max_mip_level,
+                    int* lw, int* lh, int64_t* off, int64_t* total)
+{
+    int w = tex_w, h = tex_h, level = 0;
+    int64_t tot = 0;
+    const int c = cube ? C * 6 : C;
+    if (lw) lw[0] = w;
+    if (lh) lh[0] = h;
+    if (off) off[0] = -1;
+    if (max_mip_level != 0) {
+        while ((w | h) > 1) {                                               // texture.cpp:77-98
+            level += 1;
+            if ((w > 1 && (w & 1)) || (h > 1 && (h & 1))) return -1;
+            if (w > 1) w >>= 1;
+            if (h > 1) h >>= 1;
+            if (level < kTexMaxLevels) { if (lw) lw[level] = w; if (lh) lh[level] = h; if (off) off[level] = tot; }
+            tot += (int64_t)w * h * tex_n * c;
+            if (max_mip_level >= 0 && level == max_mip_level) break;
+        }
+    }
+    if (total) *total = tot;
+    return level;
+}
+
+static int fill_tex_params(TexParams& p, const char* who, const float* tex, const float* const* mip_ptrs_host, int L,
+                           const float* uv, const float* uv_da, const float* bias,
+                           int tex_n, int tex_h, int tex_w, int C, int N, int H, int W, int filter, int boundary)
+{
+    NVDR_REQUIRE(filter >= 0 && filter < 4, "filter_mode unsupported");
+    NVDR_REQUIRE(boundary >= 0 && boundary < 4, "boundary_mode unsupported");
+    NVDR_REQUIRE(boundary != TEX_B_CUBE, "%s: cube map textures are not implemented in this build (2D textures only)", who);
+    NVDR_REQUIRE(tex && uv, "%s: null pointer", who);
+    NVDR_REQUIRE(tex_n > 0 && tex_h > 0 && tex_w > 0 && C > 0, "tex must have shape[>0, >0, >0, >0]");
+    NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "uv must have shape [>0, >0, >0, 2]");
+    NVDR_REQUIRE(tex_n == 1 || tex_n == N, "minibatch size mismatch between inputs tex, uv");
+    NVDR_REQUIRE(tex_w <= (1 << 16) && tex_h <= (1 << 16), "texture size too large");
+    const bool mips = (filter == TEX_LMN || filter == TEX_LML);
+    if (mips) {
+        NVDR_REQUIRE(uv_da || bias, "mipmapping filter mode requires uv_da and/or mip_level_bias input");
+        NVDR_REQUIRE(L >= 0 && L < kTexMaxLevels, "%s: bad mip level count %d", who, L);
+        NVDR_REQUIRE(L == 0 || mip_ptrs_host, "mipmapping filter mode requires mip wrapper or mip stack input");
+    }
+    NVDR_REQUIRE(!((uintptr_t)uv & 7), "uv input tensor not aligned to float2");
+    NVDR_REQUIRE(!((uintptr_t)uv_da & 15), "uv_da input tensor not aligned to float4");
+    p = TexParams{};
+    p.tex[0] = tex;
+    p.levelMax = mips ? L : 0;
+    for (int i = 1; i <= p.levelMax; i++) {
+        NVDR_REQUIRE(mip_ptrs_host[i - 1], "%s: mip level %d missing", who, i);
+        p.tex[i] = mip_ptrs_host[i - 1];
+    }
+    p.uv = uv; p.uvDA = mips ? uv_da : nullptr; p.bias = mips ? bias : nullptr;
+    p.boundary = boundary; p.channels = C; p.imgW = W; p.imgH = H; p.n = N;
+    p.texW = tex_w; p.texH = tex_h; p.texDepth = tex_n;
+    p.tilesX = (W + 7) / 8; p.tilesY = (H + 7) / 8;
+    return NVDR_OK;
+}
+
+static dim3 tex_grid(const TexParams& p)
+{
+    const long long tiles = (long long)p.tilesX * p.tilesY * p.n;
+    const long long groups = (tiles + 3) / 4;
+    return dim3((unsigned)(((groups + 7) / 8) * 8));
+}
+
+}  // namespace nvdr
+
+using namespace nvdr;
+
+extern "C" int nvdr_texture_mip_info(int tex_n, int tex_h, int tex_w, int C, int cube, int max_mip_level,
+                                     int* lvl_w, int* lvl_h, int64_t* lvl_off, int64_t* total_floats)
+{
+    return mip_info(tex_n, tex_h, tex_w, C, cube, max_mip_level, lvl_w, lvl_h, lvl_off, total_floats);
+}
+
+extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h, int tex_w, int C, int cube,
+                                          int max_mip_level, float* mip, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_REQUIRE(!cube, "texture_construct_mip: cube map textures are not implemented in this build (2D textures only)");
+    NVDR_REQUIRE(max_mip_level >= -1, "invalid max_mip_level");
+    NVDR_REQUIRE(tex && tex_n > 0 && tex_h > 0 && tex_w > 0 && C > 0, "tex must have shape[>0, >0, >0, >0]");
+    NVDR_REQUIRE(tex_w <= (1 << 16) && tex_h <= (1 << 16), "texture size too large");
+    int lw[kTexMaxLevels], lh[kTexMaxLevels]; int64_t off[kTexMaxLevels], total;
+    const int L = mip_info(tex_n, tex_h, tex_w, C, 0, max_mip_level, lw, lh, off, &total);
+    if (L < 0) {                                                             // texture.cpp:15-60 raiseMipSizeError
+        set_error("texture_construct_mip: texture extents %d x %d cannot be halved down to 1 (odd size at a mip level); "
+                  "use a power-of-two size, or limit max_mip_level", tex_w, tex_h);
+        return NVDR_ERR_ARG;
+    }
+    NVDR_REQUIRE(L == 0 || mip, "texture_construct_mip: null mip buffer");
+    for (int l = 1; l <= L; l++) {
+        MipParams mp;
+        mp.in = (l == 1) ? tex : mip + off[l - 1];
+        mp.out = mip + off[l];
+        mp.wi = lw[l - 1]; mp.hi = lh[l - 1]; mp.wo = lw[l]; mp.ho = lh[l]; mp.depth = tex_n; mp.C = C;
+        const long long total_out = (long long)mp.wo * mp.ho * tex_n * C;
+        ProfileScope ps("tex_mip_build", stream);
+        hipLaunchKernelGGL(k_mip_build, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, stream, mp);
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}
+
+#define NVDR_TEX_FWD_C(FILTER, BO)                                                                        \
+    do {                                                                                                   \
+        if (vec4)        hipLaunchKernelGGL((k_tex_fwd<FILTER, BO, 4>), grid, dim3(256), 0, stream, p);    \
+        else if (C == 3) hipLaunchKernelGGL((k_tex_fwd<FILTER, BO, 3>), grid, dim3(256), 0, stream, p);    \
+        else if (vec2)   hipLaunchKernelGGL((k_tex_fwd<FILTER, BO, 2>), grid, dim3(256), 0, stream, p);    \
+        else if (C == 1) hipLaunchKernelGGL((k_tex_fwd<FILTER, BO, 1>), grid, dim3(256), 0, stream, p);    \
+        else             hipLaunchKernelGGL((k_tex_fwd<FILTER, BO, 0>), grid, dim3(256), 0, stream, p);    \
+    } while (0)
+
+extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_host, int L,
+                                const float* uv, const float* uv_da, const float* mip_level_bias,
+                                int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
+                                int filter_mode, int boundary_mode, float* out, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    TexParams p;
+    int rc = fill_tex_params(p, "texture_fwd", tex, mip_ptrs_host, L, uv, uv_da, mip_level_bias,
+                             tex_n, tex_h, tex_w, C, N, H, W, filter_mode, boundary_mode);
+    if (rc) return rc;
+    NVDR_REQUIRE(out, "texture_fwd: null output");
+    p.out = out;
+    bool vec4 = (C == 4) && !((uintptr_t)out & 15), vec2 = (C == 2) && !((uintptr_t)out & 7);
+    for (int i = 0; i <= p.levelMax; i++) { vec4 = vec4 && !((uintptr_t)p.tex[i] & 15); vec2 = vec2 && !((uintptr_t)p.tex[i] & 7); }
+    const dim3 grid = tex_grid(p);
+    const bool bo = (p.levelMax >= 0) && (filter_mode >= TEX_LMN) && !p.uvDA;
+    {
+        ProfileScope ps("tex_fwd", stream);
+        switch (filter_mode) {
+        case TEX_NEAREST: NVDR_TEX_FWD_C(TEX_NEAREST, false); break;
+        case TEX_LINEAR:  NVDR_TEX_FWD_C(TEX_LINEAR, false); break;
+        case TEX_LMN:     if (bo) NVDR_TEX_FWD_C(TEX_LMN, true); else NVDR_TEX_FWD_C(TEX_LMN, false); break;
+        default:          if (bo) NVDR_TEX_FWD_C(TEX_LML, true); else NVDR_TEX_FWD_C(TEX_LML, false); break;
+        }
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}
+
+extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_host, int L,
+                                 const float* uv, const float* uv_da, const float* mip_level_bias, const float* dy,
+                                 int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
+                                 int filter_mode, int boundary_mode, int pull_mip_grads,
+                                 float* g_tex, float* const* g_mip_ptrs_host,
+                                 float* g_uv, float* g_uv_da, float* g_mip_level_bias, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    TexParams p;
+    int rc = fill_tex_params(p, "texture_grad", tex, mip_ptrs_host, L, uv, uv_da, mip_level_bias,
+                             tex_n, tex_h, tex_w, C, N, H, W, filter_mode, boundary_mode);
+    if (rc) return rc;
+    NVDR_REQUIRE(dy && g_tex, "texture_grad: null pointer");
+    NVDR_REQUIRE(filter_mode == TEX_NEAREST || g_uv, "texture_grad: g_uv missing");
+    NVDR_REQUIRE(!((uintptr_t)g_uv & 7), "grad_uv output tensor not aligned to float2");
+    NVDR_REQUIRE(!((uintptr_t)g_uv_da & 15), "grad_uv_da output tensor not aligned to float4");
+    p.dy = dy;
+    p.gradTex[0] = g_tex;
+    for (int i = 1; i <= p.levelMax; i++) {
+        NVDR_REQUIRE(g_mip_ptrs_host && g_mip_ptrs_host[i - 1], "texture_grad: gradient buffer of mip level %d missing", i);
+        p.gradTex[i] = g_mip_ptrs_host[i - 1];
+    }
+    p.gradUV = g_uv;
+    p.gradUVDA = (filter_mode == TEX_LML && p.uvDA) ? g_uv_da : nullptr;
+    p.gradBias = (filter_mode == TEX_LML && p.bias) ? g_mip_level_bias : nullptr;
+    NVDR_REQUIRE(!(filter_mode == TEX_LML && p.uvDA) || g_uv_da, "texture_grad: g_uv_da missing");
+    NVDR_REQUIRE(!(filter_mode == TEX_LML && p.bias) || g_mip_level_bias, "texture_grad: g_mip_level_bias missing");
+    const dim3 grid = tex_grid(p);
+    const bool bo = (filter_mode >= TEX_LMN) && !p.uvDA;
+    {
+        ProfileScope ps("tex_grad", stream);
+        switch (filter_mode) {
+        case TEX_NEAREST: hipLaunchKernelGGL((k_tex_grad<TEX_NEAREST, false>), grid, dim3(256), 0, stream, p); break;
+        case TEX_LINEAR:  hipLaunchKernelGGL((k_tex_grad<TEX_LINEAR, false>), grid, dim3(256), 0, stream, p); break;
+        case TEX_LMN:     if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LMN, true>), grid, dim3(256), 0, stream, p);
+                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LMN, false>), grid, dim3(256), 0, stream, p); break;
+        default:          if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LML, true>), grid, dim3(256), 0, stream, p);
+                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LML, false>), grid, dim3(256), 0, stream, p); break;
+        }
+    }
+    NVDR_LAUNCH_CHECK();
+    if (pull_mip_grads && p.levelMax > 0) {                                  // torch_texture.cpp:679-687
+        MipGradParams mg;
+        for (int i = 0; i <= p.levelMax; i++) mg.gradTex[i] = p.gradTex[i];
+        mg.texW = tex_w; mg.texH = tex_h; mg.depth = tex_n; mg.C = C; mg.levelMax = p.levelMax;
+        const long long total = (long long)tex_w * tex_h * tex_n * C;
+        ProfileScope ps("tex_mip_grad", stream);
+        hipLaunchKernelGGL(k_mip_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mg);
+        NVDR_LAUNCH_CHECK();
+    }
+    return NVDR_OK;
+}

@@ -343,3 +343,317 @@ def interpolate_grad(attr, rast, tri, dy):
     """torch_interpolate.cpp:242-248."""
     g_attr, g_rast, _ = interpolate_grad_da(attr, rast, tri, dy, None, None, False, [])
     return g_attr, g_rast
+
+
+# ----------------------------------------------------------------------------- texture
+
+_TEX_MAX_LEVELS = 17
+_FILTER_NEAREST, _FILTER_LINEAR, _FILTER_LMN, _FILTER_LML = 0, 1, 2, 3
+_BOUNDARY_CUBE = 0
+
+
+class TextureMipWrapper:
+    """Opaque mip stack (reference: csrc/torch/torch_types.h:28-35): one flat f32 tensor holding
+    levels 1..L plus the metadata the consistency checks need (torch_texture.cpp:309-310)."""
+
+    def __init__(self):
+        self.mip = None
+        self.max_mip_level = 0
+        self.texture_size = []
+        self.cube_mode = False
+
+
+def _mip_info(tex_shape, cube_mode, max_mip_level, fn):
+    import ctypes
+    lw = (ctypes.c_int * _TEX_MAX_LEVELS)(); lh = (ctypes.c_int * _TEX_MAX_LEVELS)()
+    off = (ctypes.c_int64 * _TEX_MAX_LEVELS)(); total = ctypes.c_int64(0)
+    n, h, w, c = (tex_shape[0], tex_shape[2], tex_shape[3], tex_shape[4]) if cube_mode else tuple(tex_shape)
+    L = _capi.load().nvdr_texture_mip_info(int(n), int(h), int(w), int(c), int(cube_mode), int(max_mip_level), lw, lh, off, ctypes.byref(total))
+    if L < 0:
+        # texture.cpp:15-60 raiseMipSizeError
+        _fail(fn, f"unsupported texture size {w}x{h}: every mip level must have even (or unit) extents; "
+                  f"use power-of-two sizes or limit max_mip_level")
+    return L, list(lw[:L + 1]), list(lh[:L + 1]), list(off[:L + 1]), int(total.value)
+
+
+def _check_tex_shape(fn, tex, cube_mode):
+    if not cube_mode:
+        _require(tex.dim() == 4 and all(s > 0 for s in tex.shape), fn, "tex must have shape[>0, >0, >0, >0]")
+    else:
+        _require(tex.dim() == 5 and tex.size(0) > 0 and tex.size(1) == 6 and tex.size(2) > 0 and tex.size(3) > 0 and tex.size(4) > 0,
+                 fn, "tex must have shape[>0, 6, >0, >0, >0] in cube map mode")
+        _require(tex.size(2) == tex.size(3), fn, "texture shape must be square in cube map mode")
+        _fail(fn, "cube map textures are not implemented in this build (2D textures only)")
+
+
+def texture_construct_mip(tex, max_mip_level, cube_mode):
+    """torch_texture.cpp:98-169."""
+    fn = "texture_construct_mip"
+    _require(max_mip_level >= -1, fn, "invalid max_mip_level")
+    dev = _check_device(fn, tex=tex)
+    _check_contiguous(fn, tex=tex)
+    _check_f32(fn, tex=tex)
+    _check_tex_shape(fn, tex, cube_mode)
+    L, lw, lh, off, total = _mip_info(tex.shape, cube_mode, max_mip_level, fn)
+    with torch.cuda.device(dev):
+        mip = torch.empty((total,), dtype=torch.float32, device=dev)
+        rc = _capi.load().nvdr_texture_construct_mip(tex.data_ptr(), tex.size(0), tex.size(1), tex.size(2), tex.size(3),
+                                                     int(cube_mode), int(max_mip_level), mip.data_ptr(), _stream(dev))
+    _capi.check(rc, fn)
+    w = TextureMipWrapper()
+    w.mip = mip
+    w.max_mip_level = int(max_mip_level)
+    w.texture_size = list(tex.shape)
+    w.cube_mode = bool(cube_mode)
+    return w
+
+
+def _has(t):
+    return t is not None and t.numel() > 0
+
+
+def _texture_common(fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, grad_mips):
+    """Validation shared by forward and backward (torch_texture.cpp:174-343, 421-604).
+    Returns (dev, enable_mip, has_uv_da, has_bias, level tensors/views, grad level tensors, grad_mip flat)."""
+    _require(0 <= filter_mode < 4, fn, "filter_mode unsupported")
+    _require(0 <= boundary_mode < 4, fn, "boundary_mode unsupported")
+    enable_mip = filter_mode in (_FILTER_LMN, _FILTER_LML)
+    has_stack = len(mip_stack) > 0
+    mip_w = mip_wrapper.mip if mip_wrapper is not None else None
+    max_mip_level = len(mip_stack) if has_stack else (mip_wrapper.max_mip_level if mip_wrapper is not None else 0)
+    has_uv_da, has_bias = _has(uv_da), _has(mip_level_bias)
+    if enable_mip:
+        _require(max_mip_level >= -1, fn, "invalid max_mip_level")
+        _require(has_uv_da or has_bias, fn, "mipmapping filter mode requires uv_da and/or mip_level_bias input")
+        _require(has_stack or mip_w is not None, fn, "mipmapping filter mode requires mip wrapper or mip stack input")
+    dev = _check_device(fn, tex=tex, uv=uv)
+    _check_contiguous(fn, tex=tex, uv=uv)
+    _check_f32(fn, tex=tex, uv=uv)
+    if enable_mip:
+        if has_stack:
+            for t in mip_stack:
+                if not t.is_cuda or t.device != dev:
+                    _fail(fn, "Mip stack inputs must reside on the correct GPU device")
+                if not t.is_contiguous():
+                    _fail(fn, "Mip stack inputs must be contiguous tensors")
+                if t.dtype != torch.float32:
+                    _fail(fn, "Mip stack inputs must be float32 tensors")
+        else:
+            _check_device(fn, mip_w=mip_w); _check_contiguous(fn, mip_w=mip_w); _check_f32(fn, mip_w=mip_w)
+        if has_uv_da:
+            _check_device(fn, uv_da=uv_da); _check_contiguous(fn, uv_da=uv_da); _check_f32(fn, uv_da=uv_da)
+        if has_bias:
+            _check_device(fn, mip_level_bias=mip_level_bias); _check_contiguous(fn, mip_level_bias=mip_level_bias)
+            _check_f32(fn, mip_level_bias=mip_level_bias)
+
+    cube_mode = boundary_mode == _BOUNDARY_CUBE
+    _check_tex_shape(fn, tex, cube_mode)
+    _require(uv.dim() == 4 and uv.size(0) > 0 and uv.size(1) > 0 and uv.size(2) > 0 and uv.size(3) == 2, fn,
+             "uv must have shape [>0, >0, >0, 2]")
+    _require(tex.size(0) == 1 or tex.size(0) == uv.size(0), fn, "minibatch size mismatch between inputs tex, uv")
+    _require(tex.size(2) <= (1 << 16) and tex.size(1) <= (1 << 16), fn, "texture size too large")
+    n, H, W = uv.size(0), uv.size(1), uv.size(2)
+    if enable_mip:
+        if has_uv_da:
+            _require(uv_da.dim() == 4 and tuple(uv_da.shape) == (n, H, W, 4), fn,
+                     "uv_da must have shape [minibatch_size, height, width, 4]")
+        if has_bias:
+            _require(mip_level_bias.dim() == 3 and tuple(mip_level_bias.shape) == (n, H, W), fn,
+                     "mip_level_bias must have shape [minibatch_size, height, width]")
+
+    levels, g_levels, g_flat = [], [], None
+    if enable_mip:
+        if has_stack:
+            for i, t in enumerate(mip_stack, start=1):
+                sw, sh = max(tex.size(2) >> i, 1), max(tex.size(1) >> i, 1)
+                _require(t.dim() == 4 and t.size(0) == tex.size(0) and t.size(1) == sh and t.size(2) == sw and t.size(3) == tex.size(3),
+                         fn, "mip level size mismatch in custom mip stack")
+                if sw == 1 and sh == 1:
+                    _require(i == len(mip_stack), fn, "mip level size mismatch in mip stack")
+                levels.append(t)
+            _require(len(levels) < _TEX_MAX_LEVELS, fn, "too many levels in custom mip stack")
+            if grad_mips:
+                g_levels = [torch.zeros_like(t) for t in mip_stack]
+        else:
+            L, lw, lh, off, total = _mip_info(tex.shape, cube_mode, max_mip_level, fn)
+            _require(list(tex.shape) == list(mip_wrapper.texture_size) and cube_mode == mip_wrapper.cube_mode, fn,
+                     "mip does not match texture size")
+            _require(mip_w.dim() == 1 and mip_w.size(0) == total, fn, "wrapped mip tensor size mismatch")
+            cnt = [tex.size(0) * lh[i] * lw[i] * tex.size(3) for i in range(L + 1)]
+            levels = [mip_w[off[i]:off[i] + cnt[i]] for i in range(1, L + 1)]
+            if grad_mips:
+                g_flat = torch.zeros_like(mip_w)
+                g_levels = [g_flat[off[i]:off[i] + cnt[i]] for i in range(1, L + 1)]
+    return dev, enable_mip, has_uv_da, has_bias, levels, g_levels, g_flat
+
+
+def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode):
+    """torch_texture.cpp:174-407."""
+    fn = "texture_fwd_mip"
+    dev, enable_mip, has_uv_da, has_bias, levels, _, _ = _texture_common(
+        fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, list(mip_stack), filter_mode, boundary_mode, False)
+    n, H, W, C = uv.size(0), uv.size(1), uv.size(2), tex.size(3)
+    ptrs, L = _capi.ptr_array(levels)
+    with torch.cuda.device(dev):
+        out = torch.empty((n, H, W, C), dtype=torch.float32, device=dev)
+        rc = _capi.load().nvdr_texture_fwd(tex.data_ptr(), ptrs, L, uv.data_ptr(),
+                                           uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
+                                           mip_level_bias.data_ptr() if (enable_mip and has_bias) else None,
+                                           tex.size(0), tex.size(1), tex.size(2), C, n, H, W,
+                                           int(filter_mode), int(boundary_mode), out.data_ptr(), _stream(dev))
+    _capi.check(rc, fn)
+    return out
+
+
+def texture_fwd(tex, uv, filter_mode, boundary_mode):
+    """torch_texture.cpp:411-416."""
+    return texture_fwd_mip(tex, uv, None, None, None, [], filter_mode, boundary_mode)
+
+
+def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode):
+    """torch_texture.cpp:421-690 -> (g_tex, g_uv, g_uv_da, g_mip_level_bias, [g_mip...])."""
+    fn = "texture_grad_linear_mipmap_linear"
+    mip_stack = list(mip_stack)
+    dev, enable_mip, has_uv_da, has_bias, levels, g_levels, g_flat = _texture_common(
+        fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, True)
+    _check_device(fn, dy=dy)
+    _check_f32(fn, dy=dy)
+    n, H, W, C = uv.size(0), uv.size(1), uv.size(2), tex.size(3)
+    _require(dy.dim() == 4 and tuple(dy.shape) == (n, H, W, C), fn, "dy must have shape [minibatch_size, height, width, channels]")
+    dy_ = dy.contiguous()
+    has_stack = len(mip_stack) > 0
+    ptrs, L = _capi.ptr_array(levels)
+    gptrs, _ = _capi.ptr_array(g_levels)
+    with torch.cuda.device(dev):
+        g_tex = torch.zeros_like(tex)
+        g_uv = g_uv_da = g_bias = None
+        if filter_mode != _FILTER_NEAREST:
+            g_uv = torch.empty_like(uv)
+            if filter_mode == _FILTER_LML:
+                if has_uv_da:
+                    g_uv_da = torch.empty_like(uv_da)
+                if has_bias:
+                    g_bias = torch.empty_like(mip_level_bias)
+        rc = _capi.load().nvdr_texture_grad(tex.data_ptr(), ptrs, L, uv.data_ptr(),
+                                            uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
+                                            mip_level_bias.data_ptr() if (enable_mip and has_bias) else None,
+                                            dy_.data_ptr(), tex.size(0), tex.size(1), tex.size(2), C, n, H, W,
+                                            int(filter_mode), int(boundary_mode), int(enable_mip and not has_stack),
+                                            g_tex.data_ptr(), gptrs, _capi.ptr(g_uv), _capi.ptr(g_uv_da), _capi.ptr(g_bias),
+                                            _stream(dev))
+    _capi.check(rc, fn)
+    return g_tex, g_uv, g_uv_da, g_bias, (g_levels if has_stack else [])
+
+
+def texture_grad_nearest(tex, uv, dy, filter_mode, boundary_mode):
+    """torch_texture.cpp:692-698."""
+    return texture_grad_linear_mipmap_linear(tex, uv, dy, None, None, None, [], filter_mode, boundary_mode)[0]
+
+
+def texture_grad_linear(tex, uv, dy, filter_mode, boundary_mode):
+    """torch_texture.cpp:700-706."""
+    r = texture_grad_linear_mipmap_linear(tex, uv, dy, None, None, None, [], filter_mode, boundary_mode)
+    return r[0], r[1]
+
+
+def texture_grad_linear_mipmap_nearest(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode):
+    """torch_texture.cpp:708-713."""
+    r = texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode)
+    return r[0], r[1], r[4]
+
+
+# ----------------------------------------------------------------------------- antialias
+
+class TopologyHashWrapper:
+    """Opaque edge -> opposite-vertex table (reference: csrc/torch/torch_types.h:37-45)."""
+
+    def __init__(self):
+        self.ev_hash = None
+
+
+def antialias_construct_topology_hash(tri):
+    """torch_antialias.cpp:25-63."""
+    fn = "antialias_construct_topology_hash"
+    dev = _check_device(fn, tri=tri)
+    _check_contiguous(fn, tri=tri)
+    _check_i32(fn, tri=tri)
+    _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
+    lib = _capi.load()
+    nbytes = lib.nvdr_antialias_hash_bytes(tri.size(0))
+    with torch.cuda.device(dev):
+        ev_hash = torch.empty((nbytes // 4,), dtype=torch.int32, device=dev)        # cleared by the library
+        rc = lib.nvdr_antialias_construct_topology_hash(tri.data_ptr(), tri.size(0), ev_hash.data_ptr(), nbytes, _stream(dev))
+    _capi.check(rc, fn)
+    w = TopologyHashWrapper()
+    w.ev_hash = ev_hash
+    return w
+
+
+def _aa_checks(fn, color, rast, pos, tri, dy=None):
+    instance_mode = pos.dim() > 2
+    _require(color.dim() == 4 and all(s > 0 for s in color.shape), fn, "color must have shape[>0, >0, >0, >0]")
+    _require(rast.dim() == 4 and rast.size(0) > 0 and rast.size(1) > 0 and rast.size(2) > 0 and rast.size(3) == 4, fn,
+             "rast must have shape[>0, >0, >0, 4]")
+    _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
+    _require(color.size(1) == rast.size(1) and color.size(2) == rast.size(2), fn,
+             "color and rast inputs must have same spatial dimensions")
+    if dy is not None:
+        _require(dy.dim() == 4 and all(s > 0 for s in dy.shape), fn, "dy must have shape[>0, >0, >0, >0]")
+        _require(color.size(1) == dy.size(1) and color.size(2) == dy.size(2) and color.size(3) == dy.size(3), fn,
+                 "color and dy inputs must have same dimensions")
+    if instance_mode:
+        _require(pos.dim() == 3 and pos.size(0) > 0 and pos.size(1) > 0 and pos.size(2) == 4, fn,
+                 "pos must have shape [>0, >0, 4] or [>0, 4]")
+        _require(rast.size(0) == color.size(0) and pos.size(0) == color.size(0), fn,
+                 "minibatch size mismatch between inputs color, rast, pos")
+    else:
+        _require(pos.dim() == 2 and pos.size(0) > 0 and pos.size(1) == 4, fn, "pos must have shape [>0, >0, 4] or [>0, 4]")
+        _require(rast.size(0) == color.size(0), fn, "minibatch size mismatch between inputs color, rast")
+    if dy is not None:
+        _require(dy.size(0) == color.size(0), fn, "minibatch size mismatch between inputs dy, color, raster_out")
+    return instance_mode
+
+
+def antialias_fwd(color, rast, pos, tri, topology_hash_wrap):
+    """torch_antialias.cpp:68-155 -> (out, work_buffer)."""
+    fn = "antialias_fwd"
+    topology_hash = topology_hash_wrap.ev_hash
+    dev = _check_device(fn, color=color, rast=rast, pos=pos, tri=tri, topology_hash=topology_hash)
+    _check_contiguous(fn, color=color, rast=rast, pos=pos, tri=tri, topology_hash=topology_hash)
+    _check_f32(fn, color=color, rast=rast, pos=pos)
+    _check_i32(fn, tri=tri, topology_hash=topology_hash)
+    instance_mode = _aa_checks(fn, color, rast, pos, tri)
+    N, H, W, C = color.shape
+    V = pos.size(1 if instance_mode else 0)
+    lib = _capi.load()
+    with torch.cuda.device(dev):
+        out = torch.empty_like(color)                                                   # the library copies color into it
+        work_buffer = torch.empty((N * W * H * 8 + 4,), dtype=torch.float32, device=dev)
+        rc = lib.nvdr_antialias_fwd(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(),
+                                    topology_hash.data_ptr(), topology_hash.numel() * 4,
+                                    int(instance_mode), N, V, tri.size(0), H, W, C,
+                                    out.data_ptr(), work_buffer.data_ptr(), work_buffer.numel() * 4, _stream(dev))
+    _capi.check(rc, fn)
+    return out, work_buffer
+
+
+def antialias_grad(color, rast, pos, tri, dy, work_buffer):
+    """torch_antialias.cpp:160-241 -> (g_color, g_pos)."""
+    fn = "antialias_grad"
+    dev = _check_device(fn, color=color, rast=rast, pos=pos, tri=tri, dy=dy, work_buffer=work_buffer)
+    _check_contiguous(fn, color=color, rast=rast, pos=pos, tri=tri, work_buffer=work_buffer)
+    _check_f32(fn, color=color, rast=rast, pos=pos, dy=dy, work_buffer=work_buffer)
+    _check_i32(fn, tri=tri)
+    instance_mode = _aa_checks(fn, color, rast, pos, tri, dy)
+    N, H, W, C = color.shape
+    V = pos.size(1 if instance_mode else 0)
+    dy_ = dy.contiguous()
+    with torch.cuda.device(dev):
+        g_color = torch.empty_like(dy_)                                                  # the library copies dy into it
+        g_pos = torch.zeros_like(pos)
+        rc = _capi.load().nvdr_antialias_grad(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(),
+                                              dy_.data_ptr(), work_buffer.data_ptr(), work_buffer.numel() * 4,
+                                              int(instance_mode), N, V, tri.size(0), H, W, C,
+                                              g_color.data_ptr(), g_pos.data_ptr(), _stream(dev))
+    _capi.check(rc, fn)
+    return g_color, g_pos

@@ -15,6 +15,7 @@ from . import _plugin
 __all__ = [
     "RasterizeCudaContext", "RasterizeGLContext", "get_log_level", "set_log_level",
     "rasterize", "DepthPeeler", "interpolate",
+    "texture", "texture_construct_mip", "antialias", "antialias_construct_topology_hash",
 ]
 
 
@@ -208,6 +209,157 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
         assert isinstance(rast_db, torch.Tensor)
         return _interpolate_func_da.apply(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_list)
     return _interpolate_func.apply(attr, rast, tri)
+
+
+# ----------------------------------------------------------------------------- texture
+# reference ops.py:298-465
+
+class _texture_func_mip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, filter_mode, tex, uv, uv_da, mip_level_bias, mip_wrapper, filter_mode_enum, boundary_mode_enum, *mip_stack):
+        empty = torch.tensor([])
+        if uv_da is None:
+            uv_da = empty
+        if mip_level_bias is None:
+            mip_level_bias = empty
+        if mip_wrapper is None:
+            mip_wrapper = _plugin.TextureMipWrapper()
+        out = _plugin.texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode_enum, boundary_mode_enum)
+        ctx.save_for_backward(tex, uv, uv_da, mip_level_bias, *mip_stack)
+        ctx.saved_misc = filter_mode, mip_wrapper, filter_mode_enum, boundary_mode_enum
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        tex, uv, uv_da, mip_level_bias, *mip_stack = ctx.saved_tensors
+        filter_mode, mip_wrapper, filter_mode_enum, boundary_mode_enum = ctx.saved_misc
+        if filter_mode == 'linear-mipmap-linear':
+            g_tex, g_uv, g_uv_da, g_mip_level_bias, g_mip_stack = _plugin.texture_grad_linear_mipmap_linear(
+                tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode_enum, boundary_mode_enum)
+            return (None, g_tex, g_uv, g_uv_da, g_mip_level_bias, None, None, None) + tuple(g_mip_stack)
+        else:  # linear-mipmap-nearest
+            g_tex, g_uv, g_mip_stack = _plugin.texture_grad_linear_mipmap_nearest(
+                tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode_enum, boundary_mode_enum)
+            return (None, g_tex, g_uv, None, None, None, None, None) + tuple(g_mip_stack)
+
+
+class _texture_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, filter_mode, tex, uv, filter_mode_enum, boundary_mode_enum):
+        out = _plugin.texture_fwd(tex, uv, filter_mode_enum, boundary_mode_enum)
+        ctx.save_for_backward(tex, uv)
+        ctx.saved_misc = filter_mode, filter_mode_enum, boundary_mode_enum
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        tex, uv = ctx.saved_tensors
+        filter_mode, filter_mode_enum, boundary_mode_enum = ctx.saved_misc
+        if filter_mode == 'linear':
+            g_tex, g_uv = _plugin.texture_grad_linear(tex, uv, dy, filter_mode_enum, boundary_mode_enum)
+            return None, g_tex, g_uv, None, None
+        else:  # nearest
+            g_tex = _plugin.texture_grad_nearest(tex, uv, dy, filter_mode_enum, boundary_mode_enum)
+            return None, g_tex, None, None, None
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
+    """Texture sampling (reference ops.py:345-439).
+
+    tex: [N or 1, Ht, Wt, C] float32 (cube maps [N or 1, 6, S, S, C] with boundary_mode='cube' are not
+    implemented in this build); uv: [N,H,W,2]; uv_da: optional [N,H,W,4] image-space derivatives of uv;
+    mip_level_bias: optional [N,H,W]; mip: a ``texture_construct_mip()`` result or a list of tensors
+    (custom mip stack, levels 1..L, which then receive their own gradients); filter_mode: 'auto',
+    'nearest', 'linear', 'linear-mipmap-nearest', 'linear-mipmap-linear' ('auto' = trilinear when
+    uv_da or mip_level_bias is given, else 'linear'); boundary_mode: 'wrap', 'clamp', 'zero', 'cube';
+    max_mip_level limits the mip chain.  Returns [N,H,W,C].
+    """
+    if filter_mode == 'auto':
+        filter_mode = 'linear-mipmap-linear' if (uv_da is not None or mip_level_bias is not None) else 'linear'
+    if max_mip_level is None:
+        max_mip_level = -1
+    else:
+        max_mip_level = int(max_mip_level)
+        assert max_mip_level >= 0
+    assert isinstance(tex, torch.Tensor) and isinstance(uv, torch.Tensor)
+    if 'mipmap' in filter_mode:
+        assert isinstance(uv_da, torch.Tensor) or isinstance(mip_level_bias, torch.Tensor)
+    if max_mip_level == 0 and filter_mode in ['linear-mipmap-nearest', 'linear-mipmap-linear']:
+        filter_mode = 'linear'
+    filter_mode_dict = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
+    filter_mode_enum = filter_mode_dict[filter_mode]
+    boundary_mode_dict = {'cube': 0, 'wrap': 1, 'clamp': 2, 'zero': 3}
+    boundary_mode_enum = boundary_mode_dict[boundary_mode]
+    if 'mipmap' in filter_mode:
+        mip_wrapper, mip_stack = None, []
+        if mip is not None:
+            assert isinstance(mip, (_plugin.TextureMipWrapper, list))
+            if isinstance(mip, list):
+                assert all(isinstance(x, torch.Tensor) for x in mip)
+                mip_stack = mip
+            else:
+                mip_wrapper = mip
+        else:
+            mip_wrapper = _plugin.texture_construct_mip(tex, max_mip_level, boundary_mode == 'cube')
+    if filter_mode == 'linear-mipmap-linear' or filter_mode == 'linear-mipmap-nearest':
+        return _texture_func_mip.apply(filter_mode, tex, uv, uv_da, mip_level_bias, mip_wrapper,
+                                       filter_mode_enum, boundary_mode_enum, *mip_stack)
+    return _texture_func.apply(filter_mode, tex, uv, filter_mode_enum, boundary_mode_enum)
+
+
+def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
+    """Build the mip stack of a constant texture once (reference ops.py:442-465); pass the result as ``mip=``."""
+    assert isinstance(tex, torch.Tensor)
+    assert cube_mode is True or cube_mode is False
+    if max_mip_level is None:
+        max_mip_level = -1
+    else:
+        max_mip_level = int(max_mip_level)
+        assert max_mip_level >= 0
+    return _plugin.texture_construct_mip(tex, max_mip_level, cube_mode)
+
+
+# ----------------------------------------------------------------------------- antialias
+# reference ops.py:471-544
+
+class _antialias_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, topology_hash, pos_gradient_boost):
+        out, work_buffer = _plugin.antialias_fwd(color, rast, pos, tri, topology_hash)
+        ctx.save_for_backward(color, rast, pos, tri)
+        ctx.saved_misc = pos_gradient_boost, work_buffer
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        color, rast, pos, tri = ctx.saved_tensors
+        pos_gradient_boost, work_buffer = ctx.saved_misc
+        g_color, g_pos = _plugin.antialias_grad(color, rast, pos, tri, dy, work_buffer)
+        if pos_gradient_boost != 1.0:
+            g_pos = g_pos * pos_gradient_boost
+        return g_color, None, g_pos, None, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """Silhouette antialiasing (reference ops.py:489-526).
+
+    color: [N,H,W,C]; rast: main output of ``rasterize()``; pos, tri: as given to ``rasterize()``.
+    A vertex shared by several triangles must use one index everywhere, otherwise its edges count as
+    silhouettes.  ``topology_hash``: optional ``antialias_construct_topology_hash(tri)`` result;
+    ``pos_gradient_boost`` scales the gradient that reaches ``pos``.  Returns [N,H,W,C].
+    """
+    assert all(isinstance(x, torch.Tensor) for x in (color, rast, pos, tri))
+    if topology_hash is not None:
+        assert isinstance(topology_hash, _plugin.TopologyHashWrapper)
+    else:
+        topology_hash = _plugin.antialias_construct_topology_hash(tri)
+    return _antialias_func.apply(color, rast, pos, tri, topology_hash, pos_gradient_boost)
+
+
+def antialias_construct_topology_hash(tri):
+    """Build the topology hash of a constant triangle tensor once (reference ops.py:529-544)."""
+    assert isinstance(tri, torch.Tensor)
+    return _plugin.antialias_construct_topology_hash(tri)
 
 
 # ----------------------------------------------------------------------------- legacy GL stub

@@ -1,0 +1,219 @@
+"""GPU parity: HIP texture / antialias (through the C ABI) vs the CPU oracle, plus the whole
+four-op chain (BASELINE config 3's op graph at a size the oracle finishes in seconds).
+
+Bars: sampled values within 1e-5 abs; gradients within 1e-5 * max(1, |g|_inf).  A pixel whose
+footprint sits exactly on a mip-level boundary may pick the neighbouring level on one side
+(1-ulp difference in log2): such pixels are allowed at a rate below 1e-3 and are still continuous."""
+import numpy as np
+import pytest
+import torch
+
+from nvdiffrast_amd.utils import m10k_batch
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-5
+
+
+def _t(a, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _tol(ref):
+    return ATOL * max(1.0, float(np.abs(ref).max()))
+
+
+def _close(a, b, tol, frac=0.0):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    if frac == 0.0:
+        assert d.max() <= tol, (d.max(), tol)
+    else:
+        bad = (d > tol).mean()
+        assert bad <= frac, (bad, d.max(), tol)
+
+
+FILTERS = ["nearest", "linear", "linear-mipmap-nearest", "linear-mipmap-linear"]
+
+
+@pytest.mark.parametrize("bm", ["wrap", "clamp", "zero"])
+@pytest.mark.parametrize("fm", FILTERS)
+@pytest.mark.parametrize("C,tex_n", [(1, 1), (2, 2), (3, 1), (4, 2), (5, 1)])
+def test_texture_forward_backward(dr, oracle, fm, bm, C, tex_n):
+    rng = np.random.default_rng(100 + C)
+    N, H, W = 2, 37, 29
+    tex = rng.uniform(size=(tex_n, 32, 64, C)).astype(np.float32)
+    uv = rng.uniform(-0.3, 1.3, size=(N, H, W, 2)).astype(np.float32)
+    mip = "mipmap" in fm
+    uv_da = (rng.normal(size=(N, H, W, 4)) * 0.05).astype(np.float32) if mip else None
+    bias = rng.uniform(-0.5, 0.5, size=(N, H, W)).astype(np.float32) if mip else None
+    dy = rng.normal(size=(N, H, W, C)).astype(np.float32)
+    dy[0, :3] = 0.0                                          # all-zero upstream gradient rows take the early-out
+    kw = dict(filter_mode=fm, boundary_mode=bm)
+
+    t_tex = _t(tex).requires_grad_(True)
+    t_uv = _t(uv).requires_grad_(True)
+    t_da = _t(uv_da).requires_grad_(True) if mip else None
+    t_bias = _t(bias).requires_grad_(True) if mip else None
+    out = dr.texture(t_tex, t_uv, t_da, t_bias, **kw)
+    out.backward(_t(dy))
+
+    oo = oracle.texture(tex, uv, uv_da, bias, **kw)
+    g = oracle.texture_grad(tex, uv, dy, uv_da, bias, **kw)
+    frac = 2e-3 if mip else 0.0
+    _close(out.detach().cpu().numpy(), oo, ATOL, frac)
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), frac)
+    if fm == "nearest":
+        assert t_uv.grad is None or float(t_uv.grad.abs().max()) == 0.0
+    else:
+        _close(t_uv.grad.cpu().numpy(), g["uv"], _tol(g["uv"]) * 4, frac)
+    if fm == "linear-mipmap-linear":
+        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]) * 4, frac)
+        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]) * 4, frac)
+    elif mip:
+        assert t_da.grad is None and t_bias.grad is None
+
+
+def test_bias_only_and_uvda_only(dr, oracle):
+    rng = np.random.default_rng(7)
+    tex = rng.uniform(size=(1, 64, 64, 3)).astype(np.float32)
+    uv = rng.uniform(size=(2, 16, 16, 2)).astype(np.float32)
+    uv_da = (rng.normal(size=(2, 16, 16, 4)) * 0.04).astype(np.float32)
+    bias = rng.uniform(0.0, 4.0, size=(2, 16, 16)).astype(np.float32)
+    for da, b in ((uv_da, None), (None, bias)):
+        for fm in ("linear-mipmap-nearest", "linear-mipmap-linear"):
+            o = dr.texture(_t(tex), _t(uv), None if da is None else _t(da), None if b is None else _t(b), filter_mode=fm)
+            _close(o.cpu().numpy(), oracle.texture(tex, uv, da, b, filter_mode=fm), ATOL, 2e-3)
+    # max_mip_level limits the chain; 0 degrades to plain bilinear (ops.py:411-412)
+    o = dr.texture(_t(tex), _t(uv), _t(uv_da), filter_mode="linear-mipmap-linear", max_mip_level=2)
+    _close(o.cpu().numpy(), oracle.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear", max_mip_level=2), ATOL, 2e-3)
+    o = dr.texture(_t(tex), _t(uv), _t(uv_da), filter_mode="linear-mipmap-linear", max_mip_level=0)
+    _close(o.cpu().numpy(), oracle.texture(tex, uv, filter_mode="linear"), ATOL)
+
+
+def test_mip_construction_and_reuse(dr, oracle):
+    rng = np.random.default_rng(8)
+    for shape in [(2, 64, 16, 3), (1, 8, 128, 4), (1, 2, 2, 1)]:
+        tex = rng.uniform(size=shape).astype(np.float32)
+        w = dr.texture_construct_mip(_t(tex))
+        levels = oracle.texture_build_mip(tex)
+        flat = np.concatenate([l.reshape(-1) for l in levels]) if levels else np.zeros(0, np.float32)
+        assert w.mip.numel() == flat.size
+        assert np.abs(w.mip.cpu().numpy() - flat).max() <= 1e-6
+    tex = rng.uniform(size=(1, 32, 32, 2)).astype(np.float32)
+    uv = rng.uniform(size=(1, 9, 9, 2)).astype(np.float32)
+    da = (rng.normal(size=(1, 9, 9, 4)) * 0.06).astype(np.float32)
+    w = dr.texture_construct_mip(_t(tex))
+    a = dr.texture(_t(tex), _t(uv), _t(da), mip=w)
+    b = dr.texture(_t(tex), _t(uv), _t(da))
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        dr.texture_construct_mip(_t(rng.uniform(size=(1, 12, 8, 1)).astype(np.float32)))     # 12 -> 6 -> 3: odd
+    with pytest.raises(RuntimeError, match="mip does not match texture size"):
+        dr.texture(_t(rng.uniform(size=(1, 16, 16, 2)).astype(np.float32)), _t(uv), _t(da), mip=w)
+    with pytest.raises(RuntimeError, match="cube"):
+        dr.texture(torch.zeros(1, 6, 4, 4, 3, device="cuda"), torch.zeros(1, 2, 2, 3, device="cuda"), boundary_mode="cube")
+
+
+def test_custom_mip_stack_gradients(dr, oracle):
+    rng = np.random.default_rng(9)
+    tex = rng.uniform(size=(1, 16, 16, 2)).astype(np.float32)
+    levels = [rng.uniform(size=(1, 16 >> k, 16 >> k, 2)).astype(np.float32) for k in range(1, 4)]
+    uv = rng.uniform(size=(2, 11, 13, 2)).astype(np.float32)
+    bias = rng.uniform(0.1, 2.9, size=(2, 11, 13)).astype(np.float32)
+    dy = rng.normal(size=(2, 11, 13, 2)).astype(np.float32)
+    t_tex = _t(tex).requires_grad_(True)
+    t_lv = [_t(l).requires_grad_(True) for l in levels]
+    out = dr.texture(t_tex, _t(uv), None, _t(bias), mip=t_lv, filter_mode="linear-mipmap-linear")
+    out.backward(_t(dy))
+    g = oracle.texture_grad(tex, uv, dy, None, bias, mip=levels, filter_mode="linear-mipmap-linear")
+    _close(out.detach().cpu().numpy(), oracle.texture(tex, uv, None, bias, mip=levels, filter_mode="linear-mipmap-linear"), ATOL, 2e-3)
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), 2e-3)
+    for k in range(3):
+        _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]), 2e-3)
+
+
+# ------------------------------------------------------------------------------ antialias
+
+def _scene(N=2, res=(96, 128), seed=31):
+    b = m10k_batch(N, seed=seed, nx=24, ny=12)
+    return b, res
+
+
+def test_antialias_forward_backward(dr, oracle):
+    b, res = _scene()
+    rng = np.random.default_rng(1)
+    ro, _ = oracle.rasterize(b["pos"], b["tri"], res)
+    color = rng.uniform(size=(2,) + res + (3,)).astype(np.float32)
+    dy = rng.normal(size=color.shape).astype(np.float32)
+    t_col = _t(color).requires_grad_(True)
+    t_pos = _t(b["pos"]).requires_grad_(True)
+    tri = _t(b["tri"])
+    out = dr.antialias(t_col, _t(ro), t_pos, tri)
+    out.backward(_t(dy))
+    oo = oracle.antialias(color, ro, b["pos"], b["tri"])
+    gc, gp = oracle.antialias_grad(color, ro, b["pos"], b["tri"], dy)
+    assert (oo != color).any(-1).sum() > 200                      # the scene has silhouettes
+    _close(out.detach().cpu().numpy(), oo, ATOL)
+    _close(t_col.grad.cpu().numpy(), gc, _tol(gc))
+    _close(t_pos.grad.cpu().numpy(), gp, _tol(gp) * 4)
+    # prebuilt topology hash and gradient boost
+    h = dr.antialias_construct_topology_hash(tri)
+    t_pos2 = _t(b["pos"]).requires_grad_(True)
+    out2 = dr.antialias(_t(color), _t(ro), t_pos2, tri, topology_hash=h, pos_gradient_boost=3.0)
+    out2.backward(_t(dy))
+    _close(out2.detach().cpu().numpy(), oo, ATOL)
+    _close(t_pos2.grad.cpu().numpy(), 3.0 * gp, _tol(gp) * 12)
+
+
+def test_antialias_range_mode_and_split_vertices(dr, oracle):
+    # shared [V,4] positions (range mode) and a mesh whose triangles do not share vertex indices
+    pos = np.array([[-0.7, -0.7, 0, 1], [0.7, -0.7, 0.2, 1], [0.7, 0.7, 0, 1], [-0.7, -0.7, 0, 1], [0.7, 0.7, 0, 1], [-0.7, 0.7, -0.1, 1]], np.float32)
+    tri = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    ranges = np.array([[0, 2], [1, 1]], np.int32)
+    res = (40, 56)
+    ro, _ = oracle.rasterize(pos, tri, res, ranges=ranges)
+    rng = np.random.default_rng(2)
+    color = rng.uniform(size=(2,) + res + (4,)).astype(np.float32)
+    dy = rng.normal(size=color.shape).astype(np.float32)
+    t_pos = _t(pos).requires_grad_(True)
+    out = dr.antialias(_t(color), _t(ro), t_pos, _t(tri))
+    out.backward(_t(dy))
+    _close(out.detach().cpu().numpy(), oracle.antialias(color, ro, pos, tri), ATOL)
+    gc, gp = oracle.antialias_grad(color, ro, pos, tri, dy)
+    _close(t_pos.grad.cpu().numpy(), gp, _tol(gp) * 4)
+
+
+def test_full_chain_config3(dr, oracle):
+    """rasterize -> interpolate(uv, diff_attrs='all') -> texture(trilinear) -> antialias, forward and
+    backward, against the oracle chain (BASELINE config 3's graph, reduced size)."""
+    N, res = 2, (128, 128)
+    b = m10k_batch(N, seed=41, nx=40, ny=20)
+    rng = np.random.default_rng(3)
+    tex = rng.uniform(size=(1, 256, 256, 3)).astype(np.float32)
+    G = rng.normal(size=(N,) + res + (3,)).astype(np.float32)
+    pos = _t(b["pos"]).requires_grad_(True)
+    uvattr = _t(b["uv"]).requires_grad_(True)
+    t_tex = _t(tex).requires_grad_(True)
+    tri = _t(b["tri"])
+    ctx = dr.RasterizeCudaContext()
+    rast, rast_db = dr.rasterize(ctx, pos, tri, res)
+    uv, uv_da = dr.interpolate(uvattr, rast, tri, rast_db=rast_db, diff_attrs="all")
+    col = dr.texture(t_tex, uv, uv_da, filter_mode="linear-mipmap-linear")
+    out = dr.antialias(col, rast, pos, tri)
+    out.backward(_t(G))
+
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    uvo, uvdao = oracle.interpolate(b["uv"], ro, b["tri"], rast_db=rdbo, diff_attrs="all")
+    colo = oracle.texture(tex, uvo, uvdao, filter_mode="linear-mipmap-linear")
+    outo = oracle.antialias(colo, ro, b["pos"], b["tri"])
+    assert (rast[..., 3].detach().cpu().numpy() != ro[..., 3]).sum() == 0
+    _close(uv_da.detach().cpu().numpy(), uvdao, _tol(uvdao))
+    _close(col.detach().cpu().numpy(), colo, 2e-5, 2e-3)
+    _close(out.detach().cpu().numpy(), outo, 2e-5, 2e-3)
+
+    g_col, g_pos_aa = oracle.antialias_grad(colo, ro, b["pos"], b["tri"], G)
+    tg = oracle.texture_grad(tex, uvo, g_col, uvdao, filter_mode="linear-mipmap-linear")
+    g_uvattr, g_rast, g_rdb = oracle.interpolate_grad(b["uv"], ro, b["tri"], tg["uv"], rast_db=rdbo, dda=tg["uv_da"], diff_attrs="all")
+    g_pos = oracle.rasterize_grad(b["pos"], b["tri"], ro, g_rast, ddb=g_rdb) + g_pos_aa
+    _close(t_tex.grad.cpu().numpy(), tg["tex"], _tol(tg["tex"]) * 4, 2e-3)
+    _close(uvattr.grad.cpu().numpy(), g_uvattr, _tol(g_uvattr) * 8, 5e-3)
+    _close(pos.grad.cpu().numpy(), g_pos, _tol(g_pos) * 8, 5e-3)
