@@ -6,10 +6,10 @@
 //                      64-bit CAS on the key, then CAS into the first free of two value slots;
 //                      antialias.cu:82-96,139-160).  The table layout is private to this library
 //                      (the reference's TopologyHashWrapper is opaque, torch_types.h:37-45).
-//  k_aa_discontinuity  one lane per pixel in scan-line order; a wave counts its candidate
-//                      (pixel, right|down) pairs with two ballots and reserves their slots in the
-//                      work buffer with ONE atomic per wave (the reference: one per 32x8 CTA
-//                      through shared memory, :197-209).
+//  k_aa_discontinuity  workgroup = 64x32 pixel block in scan-line order; candidate (pixel, right|down)
+//                      pairs are counted per wave, and the block reserves their slots in the work
+//                      buffer with ONE returning atomic per 2048 pixels (the shared counter is the
+//                      only contended word; the reference: one atomic per 32x8 CTA, :197-209).
 //  k_aa_analysis       one lane per work item, grid-stride (item count lives on the device):
 //                      silhouette test, edge crossing, blend with hardware f32 atomics (:236-379).
 //  k_aa_grad           one lane per work item with alpha != 0 (:406-554).
@@ -112,29 +112,54 @@ __global__ __launch_bounds__(256) void k_aa_mesh(const AAParams p)
 
 // ---- discontinuity finder (antialias.cu:165-214) ------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p)
+// Workgroup = 64 x 32 pixel block (4 waves x 8 rows of 64 pixels, 1 KiB-stride coalesced reads of
+// the id channel).  Candidates are counted per wave with ballots, waves get their offsets from an
+// LDS counter, and the block reserves its slots in the work buffer with ONE global atomic, so the
+// shared counter sees one returning atomic per 2048 pixels.
+constexpr int kAaBlockW = 64, kAaBlockH = 32, kAaRows = 8;
+
+__global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p, int gx, int gy)
 {
-    const size_t total = (size_t)p.width * p.height * p.n;
-    const size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    bool c1 = false, c2 = false;
-    int px = 0, py = 0, pz = 0;
-    if (pidx < total) {
-        px = (int)(pidx % p.width);
-        const size_t t = pidx / p.width;
-        py = (int)(t % p.height);
-        pz = (int)(t / p.height);
-        const float tri0 = p.rast[pidx * 4 + 3];            // compared as floats, like the reference
-        if (px < p.width - 1)  c1 = p.rast[(pidx + 1) * 4 + 3] != tri0;
-        if (py < p.height - 1) c2 = p.rast[(pidx + p.width) * 4 + 3] != tri0;
+    __shared__ int s_total, s_base;
+    int bx, by, pz;
+    if (!decode_block(gx, gy, p.n, bx, by, pz)) return;
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = bx * kAaBlockW + lane;
+    const int row0 = by * kAaBlockH + wave * kAaRows;
+    uint32_t c1 = 0, c2 = 0;                                 // bit r: candidate (right / down) in row r of this lane
+    int cnt = 0;
+    if (px < p.width) {
+#pragma unroll
+        for (int r = 0; r < kAaRows; r++) {
+            const int py = row0 + r;
+            if (py >= p.height) break;
+            const size_t pidx = (size_t)px + (size_t)p.width * (py + (size_t)p.height * pz);
+            const float tri0 = p.rast[pidx * 4 + 3];         // compared as floats, like the reference
+            if (px < p.width - 1 && p.rast[(pidx + 1) * 4 + 3] != tri0) { c1 |= 1u << r; cnt++; }
+            if (py < p.height - 1 && p.rast[(pidx + p.width) * 4 + 3] != tri0) { c2 |= 1u << r; cnt++; }
+        }
     }
-    const uint64_t m1 = __ballot(c1), m2 = __ballot(c2);
-    const int n1 = __popcll(m1), n2 = __popcll(m2);
-    if (n1 + n2 == 0) return;
-    int base = 0;
-    if (lane_id() == 0) base = atomicAdd(&p.work[0].x, n1 + n2);
-    base = __builtin_amdgcn_readfirstlane(base) + 1;         // slot 0 holds the counters
-    if (c1) p.work[base + mask_rank(m1)] = make_int4(px, py, pz << 16, 0);
-    if (c2) p.work[base + n1 + mask_rank(m2)] = make_int4(px, py, (pz << 16) + (1 << 2), 0);
+    // Exclusive prefix of `cnt` over the wave (the order of work items is irrelevant).
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const int waveTotal = __shfl(incl, 63, 64);
+    int waveBase = 0;
+    if (lane == 0 && waveTotal) waveBase = atomicAdd(&s_total, waveTotal);
+    waveBase = __builtin_amdgcn_readfirstlane(waveBase);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_total ? atomicAdd(&p.work[0].x, s_total) : 0;
+    __syncthreads();
+    if (cnt == 0) return;
+    int idx = s_base + 1 + waveBase + (incl - cnt);          // slot 0 holds the counters
+#pragma unroll
+    for (int r = 0; r < kAaRows; r++) {
+        const int py = row0 + r;
+        if (c1 & (1u << r)) p.work[idx++] = make_int4(px, py, pz << 16, 0);
+        if (c2 & (1u << r)) p.work[idx++] = make_int4(px, py, (pz << 16) + (1 << 2), 0);
+    }
 }
 
 // ---- analysis + blend (antialias.cu:219-382) ------------------------------------------------------
@@ -401,7 +426,9 @@ extern "C" int nvdr_antialias_fwd(const float* color, const float* rast, const f
     NVDR_HIP_CHECK(hipMemsetAsync(work, 0, 16, stream));
     {
         ProfileScope ps("aa_discontinuity", stream);
-        hipLaunchKernelGGL(k_aa_discontinuity, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, p);
+        const int gx = (W + kAaBlockW - 1) / kAaBlockW, gy = (H + kAaBlockH - 1) / kAaBlockH;
+        const long long blocks = (long long)gx * gy * N;
+        hipLaunchKernelGGL(k_aa_discontinuity, dim3((unsigned)(((blocks + 7) / 8) * 8)), dim3(256), 0, stream, p, gx, gy);
     }
     NVDR_LAUNCH_CHECK();
     {

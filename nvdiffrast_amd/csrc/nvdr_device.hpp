@@ -176,12 +176,24 @@ struct FixedScale {
 struct RunScan {
     float c1, c2, c4, c8;
     bool  tail;
+    // Value of the previous lane of the 16-lane row (`fallback` in the row's first lane).
+    static __device__ __forceinline__ int prev_lane(int v, int fallback) {
+        return __builtin_amdgcn_update_dpp(fallback, v, 0x111, 0xf, 0xf, false);         // row_shr:1
+    }
     __device__ __forceinline__ RunScan(int key, bool active) {
-        const int lane = lane_id();
         if (!active) key = -1;
-        const int prev = __builtin_amdgcn_update_dpp(-2, key, 0x111, 0xf, 0xf, false);   // row_shr:1
-        const bool head = (prev != key) | !active;
-        const uint64_t H = __ballot(head) | 0x0001000100010001ull;
+        init((prev_lane(key, -2) != key) | !active, active);
+    }
+    // From a caller-made "starts a new run" predicate (callers compare several fields with prev_lane()).
+    struct FromHead {};
+    __device__ __forceinline__ RunScan(FromHead, bool head, bool active) { init(head | !active, active); }
+    __device__ __forceinline__ bool any_merge() const { return merges; }
+    bool merges;
+    __device__ __forceinline__ void init(bool head, bool active) {
+        const int lane = lane_id();
+        // Lanes that are not executing (divergent callers) count as run boundaries.
+        const uint64_t H = __ballot(head) | ~__ballot(true) | 0x0001000100010001ull;
+        merges = (~H) != 0ull;                                                            // some lane continues a run
         const uint64_t below = H & ((2ull << lane) - 1ull);                                // heads at or below me
         const int dist = lane - (63 - __builtin_clzll(below));
         c1 = dist >= 1 ? 1.f : 0.f; c2 = dist >= 2 ? 1.f : 0.f;

@@ -8,8 +8,9 @@
 //                a wave land in a compact texture footprint (L1/L2 hits); uv / uv_da / out are
 //                read and written as whole float2 / float4 per lane.  Tiles are handed to the
 //                XCDs in contiguous chunks so neighbouring tiles share an L2.
-//  k_tex_grad    same mapping; texel-weight scatter with hardware f32 atomics, uv / uv_da /
-//                bias gradients written per pixel (texture_kernel.cu:905-1140).
+//  k_tex_grad    same mapping; texel weights are accumulated in an LDS patch table (64-bit fixed
+//                point) and flushed with line-coalesced hardware f32 atomics; uv / uv_da / bias
+//                gradients are written per pixel (texture_kernel.cu:905-1140).
 //  k_mip_grad    one lane per base texel pulls its ancestors' gradients (:843-895).
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
@@ -26,7 +27,7 @@ struct TexParams {
     const float* uv; const float* uvDA; const float* bias; const float* dy;
     float* out; float* gradUV; float* gradUVDA; float* gradBias;
     int boundary, channels, imgW, imgH, n, texW, texH, texDepth, levelMax;
-    int tilesX, tilesY;
+    int tilesX, tilesY, dbg;
 };
 
 __device__ __forceinline__ int level_dim(int d, int level) { int v = d >> level; return v > 1 ? v : 1; }
@@ -46,7 +47,7 @@ __device__ __forceinline__ long long tex_index_nearest(const TexParams& p, float
     return (long long)iu + (long long)w * (iv + (long long)tz * h);
 }
 
-struct Quad { long long tc[4]; float fu, fv; };          // texel indices x0y0, x1y0, x0y1, x1y1 (or -1) and weights
+struct Quad { long long tc[4]; float fu, fv; int x0, x1, y0, y1; };   // texel indices x0y0, x1y0, x0y1, x1y1 (or -1), weights, texel coords
 
 // texture_kernel.cu:368-472.  The one explicit fma is where the reference's compiler contracts.
 __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, float v, int tz, int level)
@@ -74,6 +75,7 @@ __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, fl
         if (iu1 >= w) iu1 -= w;
         if (iv1 >= h) iv1 -= h;
     }
+    q.x0 = iu0; q.x1 = iu1; q.y0 = iv0; q.y1 = iv1;
     const long long base = (long long)tz * w * h;
     q.tc[0] = base + iu0 + (long long)w * iv0;
     q.tc[1] = base + iu1 + (long long)w * iv0;
@@ -146,24 +148,26 @@ __device__ __forceinline__ void load_texel(float* dst, const float* base, long l
     else { for (int c = 0; c < (C_CT > 0 ? C_CT : C); c++) dst[c] = s[c]; }
 }
 
-// Pixel of this lane: waves own 8x8 tiles, tiles are dealt to XCDs in contiguous chunks.
-__device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, int& pz)
+// Pixel of this lane: a workgroup owns a 16x16 pixel block (four waves = 2x2 tiles of 8x8), blocks
+// are dealt to the XCDs in contiguous chunks.  Returns false when the whole workgroup has no block;
+// `inside` tells whether this lane's pixel exists.
+__device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, int& pz, bool& inside)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long tilesPerImage = (long long)p.tilesX * p.tilesY;
-    const long long totalGroups = (tilesPerImage * p.n + 3) >> 2;            // 4 tiles (waves) per workgroup
-    const long long perXcd = (totalGroups + 7) >> 3;
+    const long long blocksPerImage = (long long)p.tilesX * p.tilesY;          // tilesX/Y count 16x16 blocks here
+    const long long total = blocksPerImage * p.n;
+    const long long perXcd = (total + 7) >> 3;
     const long long j = blockIdx.x >> 3;
-    const long long group = (long long)(blockIdx.x & 7) * perXcd + j;
-    if (j >= perXcd || group >= totalGroups) return false;
-    const long long tile = group * 4 + wave;
-    if (tile >= tilesPerImage * p.n) return false;
-    pz = (int)(tile / tilesPerImage);
-    const int rem = (int)(tile - (long long)pz * tilesPerImage);
-    const int ty = rem / p.tilesX, tx = rem - ty * p.tilesX;
-    px = tx * 8 + (lane & 7);
-    py = ty * 8 + (lane >> 3);
-    return px < p.imgW && py < p.imgH;
+    const long long blk = (long long)(blockIdx.x & 7) * perXcd + j;
+    inside = false;
+    if (j >= perXcd || blk >= total) return false;
+    pz = (int)(blk / blocksPerImage);
+    const int rem = (int)(blk - (long long)pz * blocksPerImage);
+    const int by = rem / p.tilesX, bx = rem - by * p.tilesX;
+    px = bx * 16 + (wave & 1) * 8 + (lane & 7);
+    py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    inside = px < p.imgW && py < p.imgH;
+    return true;
 }
 
 // ---- forward (texture_kernel.cu:709-800) ---------------------------------------------------
@@ -171,8 +175,8 @@ __device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, 
 template <int FILTER, bool BIAS_ONLY, int C_CT>
 __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
 {
-    int px, py, pz;
-    if (!tex_pixel(p, px, py, pz)) return;
+    int px, py, pz; bool inside;
+    if (!tex_pixel(p, px, py, pz, inside) || !inside) return;
     constexpr int CMAX = C_CT > 0 ? C_CT : 1;
     const int C = C_CT > 0 ? C_CT : p.channels;
     const int tz = (p.texDepth == 1) ? 0 : pz;
@@ -235,99 +239,233 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
 
 // ---- backward (texture_kernel.cu:905-1140) -------------------------------------------------
 
+// Texel-gradient accumulator of one workgroup: an LDS open-addressing table of 8x2-texel patches
+// keyed by (level, patch x, patch y), each patch holding 16 texels x C channels of 64-bit fixed-point
+// sums (nvdr_device.hpp: LDS integer atomics are ~30x cheaper than ds_add_f32, and a global atomic
+// costs one memory transaction per touched cache line).  Every tap of the workgroup's 16x16 pixels is
+// added here; at the end each patch row is flushed by consecutive lanes, so one atomic instruction
+// covers a few whole lines instead of 64 scattered ones, and pixels that hit the same texel (e.g. a
+// constant-uv background) cost one global atomic per workgroup instead of one per pixel.
+// The fixed-point scale comes from the block's largest |dy| (every tap weight is in [0,1]).
+struct PatchTable {
+    unsigned long long* keys;     // [groups]  0 = empty
+    unsigned long long* vals;     // [groups * 16 * C]
+    int groups, C;
+
+    __device__ __forceinline__ void clear(int tid, int nthreads) {
+        for (int i = tid; i < groups; i += nthreads) keys[i] = 0ull;
+        for (int i = tid; i < groups * 16 * C; i += nthreads) vals[i] = 0ull;
+    }
+    static __device__ __forceinline__ unsigned long long key_of(int level, int x, int y) {
+        return ((unsigned long long)(level + 1) << 58) | ((unsigned long long)(unsigned)(y >> 1) << 29) | (unsigned long long)(unsigned)(x >> 3);
+    }
+    // Index of texel (x, y) of `level` in vals (in texels, multiply by C) or -1 when the table is full.
+    __device__ __forceinline__ int find(int level, int x, int y) const {
+        const unsigned long long key = key_of(level, x, y);
+        unsigned long long k = key;
+        k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 32;
+        unsigned h = (unsigned)k;
+#pragma unroll 1
+        for (int probe = 0; probe < 8; probe++) {
+            h &= (unsigned)(groups - 1);
+            const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+            if (old == 0ull || old == key) return (int)h * 16 + (y & 1) * 8 + (x & 7);
+            h++;
+        }
+        return -1;
+    }
+};
+
 template <int FILTER, bool BIAS_ONLY>
-__global__ __launch_bounds__(256) void k_tex_grad(const TexParams p)
+__global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
 {
-    int px, py, pz;
-    if (!tex_pixel(p, px, py, pz)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     const int C = p.channels;
+    PatchTable tab{(unsigned long long*)s_mem, (unsigned long long*)s_mem + groups, groups, C};
+    uint32_t* s_max = (uint32_t*)((unsigned long long*)s_mem + groups + (size_t)groups * 16 * C);
+    int px = 0, py = 0, pz = 0; bool inside;
+    if (!tex_pixel(p, px, py, pz, inside)) return;
+    if (groups > 0 && !(p.dbg & 2048)) tab.clear(threadIdx.x, 256);
+    if (threadIdx.x == 0) *s_max = 0u;
+    __syncthreads();
+
     const int tz = (p.texDepth == 1) ? 0 : pz;
     const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
     const float* pDy = p.dy + pidx * C;
 
-    // All-zero upstream gradient: explicit zero stores, no scatter (:922-971).
-    uint32_t dmax = 0u;
-    for (int c = 0; c < C; c++) dmax |= (uint32_t)__float_as_int(pDy[c]);
-    if (__int_as_float((int)dmax) == 0.f) {
-        if (FILTER != TEX_NEAREST) ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
-        if (FILTER == TEX_LML) {
-            if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.gradBias) p.gradBias[pidx] = 0.f;
-        }
-        return;
-    }
-    const float2 uv = ((const float2*)p.uv)[pidx];
-
-    if (FILTER == TEX_NEAREST) {
-        const long long tc = tex_index_nearest(p, uv.x, uv.y, tz);
-        if (tc < 0) return;
-        float* pOut = p.gradTex[0] + tc * C;
-        for (int c = 0; c < C; c++) atomic_add_f32(pOut + c, pDy[c]);
-        return;
-    }
-
-    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
-    int level0, level1; float flevel;
-    tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, &dw);
-
-    const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
-    const float* pIn0 = p.tex[level0];
-    float* pOut0 = p.gradTex[level0];
-    const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
-    const float tw0[4] = {w000, w010, w001, w011};
-    const float sclu0 = (float)level_dim(p.texW, level0), sclv0 = (float)level_dim(p.texH, level0);
-    float gu = 0.f, gv = 0.f;
-
-    if (FILTER == TEX_LINEAR || FILTER == TEX_LMN) {
-        for (int c = 0; c < C; c++) {
-            const float d = pDy[c];
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) atomic_add_f32(pOut0 + q0.tc[k] * C + c, tw0[k] * d);
-            const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
-            const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
-            const float ad = (a11 + a00 - a10 - a01);
-            gu += d * ((a10 - a00) + q0.fv * ad) * sclu0;
-            gv += d * ((a01 - a00) + q0.fu * ad) * sclv0;
-        }
-        ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
-        return;
-    }
-
-    // Trilinear.
-    float df = 0.f;
-    const Quad q1 = tex_index_linear(p, uv.x, uv.y, tz, level1);
-    const float* pIn1 = p.tex[level1];
-    float* pOut1 = p.gradTex[level1];
-    const float w111 = q1.fu * q1.fv, w110 = q1.fu - w111, w101 = q1.fv - w111, w100 = 1.f - q1.fu - w101;
-    const float tw1[4] = {w100, w110, w101, w111};
-    const float sclu1 = (float)level_dim(p.texW, level1), sclv1 = (float)level_dim(p.texH, level1);
-    for (int c = 0; c < C; c++) {
-        const float d = pDy[c];
-        const float d0 = (1.f - flevel) * d;
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) atomic_add_f32(pOut0 + q0.tc[k] * C + c, tw0[k] * d0);
-        const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
-        const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
-        const float ad = (a11 + a00 - a10 - a01);
-        gu += d0 * ((a10 - a00) + q0.fv * ad) * sclu0;
-        gv += d0 * ((a01 - a00) + q0.fu * ad) * sclv0;
-        if (flevel > 0.f) {
-            const float d1 = flevel * d;
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (q1.tc[k] >= 0) atomic_add_f32(pOut1 + q1.tc[k] * C + c, tw1[k] * d1);
-            const float b00 = q1.tc[0] >= 0 ? pIn1[q1.tc[0] * C + c] : 0.f, b10 = q1.tc[1] >= 0 ? pIn1[q1.tc[1] * C + c] : 0.f;
-            const float b01 = q1.tc[2] >= 0 ? pIn1[q1.tc[2] * C + c] : 0.f, b11 = q1.tc[3] >= 0 ? pIn1[q1.tc[3] * C + c] : 0.f;
-            const float bd = (b11 + b00 - b10 - b01);
-            gu += d1 * ((b10 - b00) + q1.fv * bd) * sclu1;
-            gv += d1 * ((b01 - b00) + q1.fu * bd) * sclv1;
-            const float a = bilerp1(a00, a10, a01, a11, q0.fu, q0.fv);
-            const float b = bilerp1(b00, b10, b01, b11, q1.fu, q1.fv);
-            df += (b - a) * d;
+    // ---- phase A: all-zero upstream gradients take the early-out (explicit zero stores, :922-971);
+    //      the rest publish the block's largest |dy|.
+    bool active = false;
+    float m = 0.f;
+    if (inside) {
+        uint32_t dmax = 0u;
+        for (int c = 0; c < C; c++) { const float d = pDy[c]; dmax |= (uint32_t)__float_as_int(d); m = max_abs_keep_nan(m, d); }
+        active = !(__int_as_float((int)dmax) == 0.f);
+        if (!active) {
+            m = 0.f;
+            if (FILTER != TEX_NEAREST) ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
+            if (FILTER == TEX_LML) {
+                if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.gradBias) p.gradBias[pidx] = 0.f;
+            }
         }
     }
-    ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
-    if (p.gradBias) p.gradBias[pidx] = df;
-    if (!BIAS_ONLY && p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(dw.x * df, dw.y * df, dw.z * df, dw.w * df);
+    block_max_update(s_max, m);
+    __syncthreads();
+    const uint32_t maxBits = *s_max;
+    if (maxBits == 0u) return;                                   // nobody has anything to scatter
+    const bool direct = (groups == 0) || maxBits >= 0x7F800000u; // no table / inf or NaN present: plain f32 atomics
+    const FixedScale fs(direct ? 0x3F800000u : maxBits);
+
+    // One tap's contribution: LDS table when it has a slot, global atomic otherwise.
+    const bool noScatter = p.dbg & 512;
+    auto scatter = [&](int slot, int level, long long tc, int c, float v) {
+        if (noScatter) return;
+        if (slot >= 0) atomicAdd(&tab.vals[(size_t)slot * C + c], fs.to_fixed(v));
+        else atomic_add_f32(p.gradTex[level] + tc * C + c, v);
+    };
+    auto slots_of = [&](const Quad& q, int level, int* sl) {
+        // The four taps of a bilinear footprint share patches most of the time: look each patch up once.
+        sl[0] = sl[1] = sl[2] = sl[3] = -1;
+        if (direct || (p.dbg & 1024)) return;
+        if (q.tc[0] >= 0) sl[0] = tab.find(level, q.x0, q.y0);
+        if (q.tc[1] >= 0) sl[1] = (q.tc[0] >= 0 && sl[0] >= 0 && (q.x1 >> 3) == (q.x0 >> 3)) ? (sl[0] & ~7) + (q.x1 & 7) : tab.find(level, q.x1, q.y0);
+        if (q.tc[2] >= 0) sl[2] = (q.tc[0] >= 0 && sl[0] >= 0 && (q.y1 >> 1) == (q.y0 >> 1)) ? (sl[0] & ~15) + (q.y1 & 1) * 8 + (q.x0 & 7) : tab.find(level, q.x0, q.y1);
+        if (q.tc[3] >= 0) {
+            if (q.tc[2] >= 0 && sl[2] >= 0 && (q.x1 >> 3) == (q.x0 >> 3)) sl[3] = (sl[2] & ~7) + (q.x1 & 7);
+            else if (q.tc[1] >= 0 && sl[1] >= 0 && (q.y1 >> 1) == (q.y0 >> 1)) sl[3] = (sl[1] & ~15) + (q.y1 & 1) * 8 + (q.x1 & 7);
+            else sl[3] = tab.find(level, q.x1, q.y1);
+        }
+    };
+
+    // Pixels that land on exactly the same texels (constant uv: backgrounds, flat regions under
+    // magnification) would serialise on one LDS address; consecutive lanes with identical footprints
+    // are summed in registers first (RunScan) and only the last lane of a run scatters.
+    auto run_of = [&](const Quad& a, int la, const Quad& b, int lb, bool second) {
+        const int f = la | (lb << 8) | ((second ? 1 : 0) << 16);
+        int same = RunScan::prev_lane(f, -1) == f;
+        same &= (int)(RunScan::prev_lane(a.x0, 0) == a.x0) & (int)(RunScan::prev_lane(a.x1, 0) == a.x1);
+        same &= (int)(RunScan::prev_lane(a.y0, 0) == a.y0) & (int)(RunScan::prev_lane(a.y1, 0) == a.y1);
+        same &= (int)(RunScan::prev_lane(b.x0, 0) == b.x0) & (int)(RunScan::prev_lane(b.x1, 0) == b.x1);
+        same &= (int)(RunScan::prev_lane(b.y0, 0) == b.y0) & (int)(RunScan::prev_lane(b.y1, 0) == b.y1);
+        return RunScan(RunScan::FromHead{}, !same, true);
+    };
+
+    // ---- phase B --------------------------------------------------------------------------------
+    if (active) {
+        const float2 uv = ((const float2*)p.uv)[pidx];
+        if (FILTER == TEX_NEAREST) {
+            const long long tc = tex_index_nearest(p, uv.x, uv.y, tz);
+            if (tc >= 0) {
+                const long long t = tc - (long long)tz * p.texW * p.texH;
+                const int y = (int)(t / p.texW), x = (int)(t - (long long)y * p.texW);
+                const int sl = direct ? -1 : tab.find(0, x, y);
+                for (int c = 0; c < C; c++) scatter(sl, 0, tc, c, pDy[c]);
+            }
+        } else {
+            float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+            int level0, level1; float flevel;
+            tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, &dw);
+
+            const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
+            const float* pIn0 = p.tex[level0];
+            const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
+            const float tw0[4] = {w000, w010, w001, w011};
+            const float sclu0 = (float)level_dim(p.texW, level0), sclv0 = (float)level_dim(p.texH, level0);
+            int sl0[4];
+            slots_of(q0, level0, sl0);
+            float gu = 0.f, gv = 0.f;
+
+            if (FILTER == TEX_LINEAR || FILTER == TEX_LMN) {
+                const RunScan rs = run_of(q0, level0, q0, level0, false);
+                for (int c = 0; c < C; c++) {
+                    const float d = pDy[c];
+                    float v0[4] = {tw0[0] * d, tw0[1] * d, tw0[2] * d, tw0[3] * d};
+                    float z = 0.f;
+                    if (rs.any_merge()) { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], z, z); }
+                    if (rs.tail) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) scatter(sl0[k], level0, q0.tc[k], c, v0[k]);
+                    }
+                    const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
+                    const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
+                    const float ad = (a11 + a00 - a10 - a01);
+                    gu += d * ((a10 - a00) + q0.fv * ad) * sclu0;
+                    gv += d * ((a01 - a00) + q0.fu * ad) * sclv0;
+                }
+                ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+            } else {
+                // Trilinear.
+                float df = 0.f;
+                const Quad q1 = tex_index_linear(p, uv.x, uv.y, tz, level1);
+                const float* pIn1 = p.tex[level1];
+                const float w111 = q1.fu * q1.fv, w110 = q1.fu - w111, w101 = q1.fv - w111, w100 = 1.f - q1.fu - w101;
+                const float tw1[4] = {w100, w110, w101, w111};
+                const float sclu1 = (float)level_dim(p.texW, level1), sclv1 = (float)level_dim(p.texH, level1);
+                int sl1[4] = {-1, -1, -1, -1};
+                if (flevel > 0.f) slots_of(q1, level1, sl1);
+                const bool second = flevel > 0.f;
+                const RunScan rs = run_of(q0, level0, q1, level1, second);
+                for (int c = 0; c < C; c++) {
+                    const float d = pDy[c];
+                    const float d0 = (1.f - flevel) * d;
+                    const float d1s = second ? flevel * d : 0.f;
+                    float v0[4] = {tw0[0] * d0, tw0[1] * d0, tw0[2] * d0, tw0[3] * d0};
+                    float v1[4] = {tw1[0] * d1s, tw1[1] * d1s, tw1[2] * d1s, tw1[3] * d1s};
+                    float z = 0.f;
+                    if (rs.any_merge()) { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], v1[0], v1[1]); rs.scan3(v1[2], v1[3], z); }
+                    if (rs.tail) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) scatter(sl0[k], level0, q0.tc[k], c, v0[k]);
+                        if (second) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) if (q1.tc[k] >= 0) scatter(sl1[k], level1, q1.tc[k], c, v1[k]);
+                        }
+                    }
+                    const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
+                    const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
+                    const float ad = (a11 + a00 - a10 - a01);
+                    gu += d0 * ((a10 - a00) + q0.fv * ad) * sclu0;
+                    gv += d0 * ((a01 - a00) + q0.fu * ad) * sclv0;
+                    if (flevel > 0.f) {
+                        const float d1 = flevel * d;
+                        const float b00 = q1.tc[0] >= 0 ? pIn1[q1.tc[0] * C + c] : 0.f, b10 = q1.tc[1] >= 0 ? pIn1[q1.tc[1] * C + c] : 0.f;
+                        const float b01 = q1.tc[2] >= 0 ? pIn1[q1.tc[2] * C + c] : 0.f, b11 = q1.tc[3] >= 0 ? pIn1[q1.tc[3] * C + c] : 0.f;
+                        const float bd = (b11 + b00 - b10 - b01);
+                        gu += d1 * ((b10 - b00) + q1.fv * bd) * sclu1;
+                        gv += d1 * ((b01 - b00) + q1.fu * bd) * sclv1;
+                        const float a = bilerp1(a00, a10, a01, a11, q0.fu, q0.fv);
+                        const float b = bilerp1(b00, b10, b01, b11, q1.fu, q1.fv);
+                        df += (b - a) * d;
+                    }
+                }
+                ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+                if (p.gradBias) p.gradBias[pidx] = df;
+                if (!BIAS_ONLY && p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(dw.x * df, dw.y * df, dw.z * df, dw.w * df);
+            }
+        }
+    }
+    if (direct || (p.dbg & 2048)) return;
+
+    // ---- flush: consecutive lanes take consecutive (texel, channel) entries of a patch row ---------
+    __syncthreads();
+    const int perGroup = 16 * C;
+    const int n = groups * perGroup;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int g = i / perGroup;
+        const unsigned long long key = tab.keys[g];
+        if (key == 0ull) continue;
+        const unsigned long long t = tab.vals[i];
+        if (t == 0ull) continue;
+        const int r = i - g * perGroup;
+        const int tx = r / C, c = r - tx * C;
+        const int level = (int)(key >> 58) - 1;
+        const int x = (int)(key & 0x1FFFFFFFull) * 8 + (tx & 7);
+        const int y = (int)((key >> 29) & 0x1FFFFFFFull) * 2 + (tx >> 3);
+        const int w = level_dim(p.texW, level), h = level_dim(p.texH, level);
+        if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
+        atomic_add_f32(p.gradTex[level] + (((long long)tz * h + y) * w + x) * C + c, fs.to_float(t));
+    }
 }
 
 // ---- mip construction / mip gradient pull ------------------------------------------------------
@@ -435,15 +573,15 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
     p.uv = uv; p.uvDA = mips ? uv_da : nullptr; p.bias = mips ? bias : nullptr;
     p.boundary = boundary; p.channels = C; p.imgW = W; p.imgH = H; p.n = N;
     p.texW = tex_w; p.texH = tex_h; p.texDepth = tex_n;
-    p.tilesX = (W + 7) / 8; p.tilesY = (H + 7) / 8;
+    p.tilesX = (W + 15) / 16; p.tilesY = (H + 15) / 16;
+    p.dbg = debug_flags();
     return NVDR_OK;
 }
 
 static dim3 tex_grid(const TexParams& p)
 {
-    const long long tiles = (long long)p.tilesX * p.tilesY * p.n;
-    const long long groups = (tiles + 3) / 4;
-    return dim3((unsigned)(((groups + 7) / 8) * 8));
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.n;
+    return dim3((unsigned)(((blocks + 7) / 8) * 8));
 }
 
 }  // namespace nvdr
@@ -552,15 +690,21 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     NVDR_REQUIRE(!(filter_mode == TEX_LML && p.bias) || g_mip_level_bias, "texture_grad: g_mip_level_bias missing");
     const dim3 grid = tex_grid(p);
     const bool bo = (filter_mode >= TEX_LMN) && !p.uvDA;
+    // LDS patch table: as many power-of-two patches of 16 texels as fit in 64 KiB (at most 512);
+    // none (direct atomics) when even 16 patches do not fit.
+    int groups = 512;
+    while (groups >= 16 && (size_t)groups * (8 + 128 * (size_t)C) + 16 > 64 * 1024) groups >>= 1;
+    if (groups < 16 || (debug_flags() & 256)) groups = 0;
+    const size_t lds = (size_t)groups * (8 + 128 * (size_t)C) + 16;
     {
         ProfileScope ps("tex_grad", stream);
         switch (filter_mode) {
-        case TEX_NEAREST: hipLaunchKernelGGL((k_tex_grad<TEX_NEAREST, false>), grid, dim3(256), 0, stream, p); break;
-        case TEX_LINEAR:  hipLaunchKernelGGL((k_tex_grad<TEX_LINEAR, false>), grid, dim3(256), 0, stream, p); break;
-        case TEX_LMN:     if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LMN, true>), grid, dim3(256), 0, stream, p);
-                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LMN, false>), grid, dim3(256), 0, stream, p); break;
-        default:          if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LML, true>), grid, dim3(256), 0, stream, p);
-                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LML, false>), grid, dim3(256), 0, stream, p); break;
+        case TEX_NEAREST: hipLaunchKernelGGL((k_tex_grad<TEX_NEAREST, false>), grid, dim3(256), lds, stream, p, groups); break;
+        case TEX_LINEAR:  hipLaunchKernelGGL((k_tex_grad<TEX_LINEAR, false>), grid, dim3(256), lds, stream, p, groups); break;
+        case TEX_LMN:     if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LMN, true>), grid, dim3(256), lds, stream, p, groups);
+                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LMN, false>), grid, dim3(256), lds, stream, p, groups); break;
+        default:          if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LML, true>), grid, dim3(256), lds, stream, p, groups);
+                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LML, false>), grid, dim3(256), lds, stream, p, groups); break;
         }
     }
     NVDR_LAUNCH_CHECK();
