@@ -840,7 +840,7 @@ __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const flo
 }
 
 template <bool ENABLE_DB>
-__global__ __launch_bounds__(kGradThreads) void k_raster_grad(const GradParams p, int gx, int gy)
+__global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad(const GradParams p, int gx, int gy)
 {
     __shared__ uint32_t s_keys[kGradSlots];
     __shared__ unsigned long long s_vals[kGradSlots * 3];
