@@ -182,12 +182,22 @@ _BOUNDARY = {"cube": 0, "wrap": 1, "clamp": 2, "zero": 3}
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
 
+def _tex_dims(tex_shape):
+    """(n, h, w, c, cube) of a [n,h,w,c] texture or a [n,6,s,s,c] cube map."""
+    if len(tex_shape) == 5:
+        n, six, h, w, c = [int(x) for x in tex_shape]
+        assert six == 6 and h == w
+        return n, h, w, c, 1
+    n, h, w, c = [int(x) for x in tex_shape]
+    return n, h, w, c, 0
+
+
 def texture_mip_info(tex_shape, max_mip_level=-1):
     """-> (L, widths, heights, offsets_in_floats, total_floats); raises on odd extents (texture.cpp:85-86)."""
-    n, h, w, c = [int(x) for x in tex_shape]
+    n, h, w, c, cube = _tex_dims(tex_shape)
     lw = (ctypes.c_int * 17)(); lh = (ctypes.c_int * 17)(); off = (ctypes.c_int64 * 17)()
     total = ctypes.c_int64(0)
-    L = lib().nvdro_texture_mip_info(n, h, w, c, 0, int(max_mip_level), lw, lh, off, ctypes.byref(total))
+    L = lib().nvdro_texture_mip_info(n, h, w, c, cube, int(max_mip_level), lw, lh, off, ctypes.byref(total))
     if L < 0:
         raise ValueError("texture extents must be divisible by two at every mip level")
     return L, list(lw[:L + 1]), list(lh[:L + 1]), list(off[:L + 1]), int(total.value)
@@ -196,12 +206,14 @@ def texture_mip_info(tex_shape, max_mip_level=-1):
 def texture_build_mip(tex, max_mip_level=-1):
     """2x2 box mip chain -> list of arrays for levels 1..L, each [n,h,w,c] (views of one flat buffer)."""
     tex = _f32(tex)
-    n, h, w, c = tex.shape
+    n, h, w, c, cube = _tex_dims(tex.shape)
     L, lw, lh, off, total = texture_mip_info(tex.shape, max_mip_level)
     flat = np.zeros(max(total, 1), np.float32)
-    rc = lib().nvdro_texture_build_mip(_p(tex, _f32p), n, h, w, c, 0, int(max_mip_level), _p(flat, _f32p))
+    rc = lib().nvdro_texture_build_mip(_p(tex, _f32p), n, h, w, c, cube, int(max_mip_level), _p(flat, _f32p))
     assert rc == 0
-    return [flat[off[i]:off[i] + n * lh[i] * lw[i] * c].reshape(n, lh[i], lw[i], c) for i in range(1, L + 1)]
+    f = 6 if cube else 1
+    shp = (lambda i: (n, 6, lh[i], lw[i], c)) if cube else (lambda i: (n, lh[i], lw[i], c))
+    return [flat[off[i]:off[i] + n * f * lh[i] * lw[i] * c].reshape(shp(i)) for i in range(1, L + 1)]
 
 
 def _ptr_array(arrs):
@@ -234,10 +246,12 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="aut
     """Arguments as nvdiffrast.torch.texture (2D textures); ``mip`` = optional list of level arrays."""
     tex, uv, uv_da, bias, levels, _, f, b = _texture_setup(tex, uv, uv_da, mip_level_bias, mip, filter_mode, boundary_mode, max_mip_level)
     N, H, W = uv.shape[:3]
-    out = np.empty((N, H, W, tex.shape[3]), np.float32)
+    tn, th, tw, tc, cube = _tex_dims(tex.shape)
+    assert cube == (b == 0), "cube map textures need boundary_mode='cube' (and vice versa)"
+    out = np.empty((N, H, W, tc), np.float32)
     pa = _ptr_array(levels)
     rc = lib().nvdro_texture_fwd(_p(tex, _f32p), pa, len(levels), _p(uv, _f32p), _p(uv_da, _f32p), _p(bias, _f32p),
-                                 tex.shape[0], tex.shape[1], tex.shape[2], tex.shape[3], N, H, W, f, b, _p(out, _f32p))
+                                 tn, th, tw, tc, N, H, W, f, b, _p(out, _f32p))
     assert rc == 0, rc
     return out
 
@@ -255,8 +269,10 @@ def texture_grad(tex, uv, dy, uv_da=None, mip_level_bias=None, mip=None, filter_
     g_uv_da = np.zeros_like(uv_da) if (f == 3 and uv_da is not None) else None
     g_bias = np.zeros_like(bias) if (f == 3 and bias is not None) else None
     pa = _ptr_array(levels); ga = _ptr_array(g_levels)
+    tn, th, tw, tc, cube = _tex_dims(tex.shape)
+    assert cube == (b == 0), "cube map textures need boundary_mode='cube' (and vice versa)"
     rc = lib().nvdro_texture_grad(_p(tex, _f32p), pa, len(levels), _p(uv, _f32p), _p(uv_da, _f32p), _p(bias, _f32p),
-                                  _p(dy, _f32p), tex.shape[0], tex.shape[1], tex.shape[2], tex.shape[3], N, H, W, f, b,
+                                  _p(dy, _f32p), tn, th, tw, tc, N, H, W, f, b,
                                   int(not custom), _p(g_tex, _f32p), ga, _p(g_uv, _f32p), _p(g_uv_da, _f32p), _p(g_bias, _f32p))
     assert rc == 0, rc
     return dict(tex=g_tex, uv=g_uv, uv_da=g_uv_da, mip_level_bias=g_bias, mip=g_levels if custom else None)

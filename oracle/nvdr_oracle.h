@@ -94,7 +94,8 @@ int nvdro_texture_build_mip(const float* tex, int tex_n, int tex_h, int tex_w, i
                             int cube, int L, float* mip);
 
 /* texture_kernel.cu:709-800.  filter: 0 nearest, 1 linear, 2 l-m-nearest, 3 l-m-linear.
- * boundary: 0 cube, 1 wrap, 2 clamp, 3 zero.  uv_da / mip_level_bias may be NULL.
+ * boundary: 0 cube (tex [tex_n,6,S,S,C], uv 3 and uv_da 6 components per pixel), 1 wrap, 2 clamp,
+ * 3 zero.  uv_da / mip_level_bias may be NULL.
  * mip_ptrs: L pointers (levels 1..L), each [tex_n,(6,)h,w,C]; may be NULL if L == 0. */
 int nvdro_texture_fwd(const float* tex, const float* const* mip_ptrs, int L,
                       const float* uv, const float* uv_da, const float* mip_level_bias,
@@ -112,6 +113,11 @@ int nvdro_texture_grad(const float* tex, const float* const* mip_ptrs, int L,
                        int pull_mip_grads,
                        float* g_tex, float* const* g_mip_ptrs,
                        float* g_uv, float* g_uv_da, float* g_mip_level_bias);
+
+/* Test hooks: cube-map face lookup and the edge fold (texel index x + w*(y + w*face), -1 = the texel
+ * that does not exist at a cube corner). */
+long long nvdro_cube_texel(int face, int ix, int iy, int w);
+int nvdro_cube_index(const float* v, float* s, float* t);
 
 /* ---- antialias -------------------------------------------------------------- */
 

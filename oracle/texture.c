@@ -9,7 +9,12 @@
  * accumulated in f64 in pixel order.  The one fused multiply-add written out below
  * (texel-space coordinate u*w - 0.5) is where nvcc contracts by default; the HIP kernels use the
  * same explicit fma so both sides agree to the last bit on texel weights.
- * Cube maps (boundary mode 0) are not restated yet: every entry point returns -2 for them.
+ * Cube maps (texture_kernel.cu:31-317) are restated from the geometry rather than from the
+ * reference's bit tables: the face table below is the OpenGL convention the reference implements
+ * (s = sa*ss/(2|c|) + 1/2, t = ta*ts/(2|c|) + 1/2), its gradient functions are the derivatives of that
+ * map, and texels beyond a face edge are folded onto the neighbouring face with integer geometry.
+ * One deliberate difference: the texel missing at a cube corner is always flagged; the reference
+ * loses the flag for slices tz >= 1 (it adds 6*tz*w*h to the negative index, :431-432).
  */
 #include "nvdr_oracle.h"
 
@@ -54,9 +59,9 @@ int nvdro_texture_mip_info(int tex_n, int tex_h, int tex_w, int C, int cube, int
 int nvdro_texture_build_mip(const float* tex, int tex_n, int tex_h, int tex_w, int C,
                             int cube, int L, float* mip)
 {
-    if (cube) return -2;
     int lw[MAX_LEVELS], lh[MAX_LEVELS];
     int64_t off[MAX_LEVELS], total;
+    if (cube) tex_n *= 6;                                                   /* six faces per slice */
     int levels = nvdro_texture_mip_info(tex_n, tex_h, tex_w, C, 0, L, lw, lh, off, &total);
     if (levels < 0) return -1;
     for (int l = 1; l <= levels; l++) {
@@ -144,14 +149,168 @@ static void index_linear(const TexCfg* t, float u, float v, int tz, int level, i
 
 static int finite4(const float* a) { return isfinite(a[0]) && isfinite(a[1]) && isfinite(a[2]) && isfinite(a[3]); }
 
-/* texture_kernel.cu:477-585.  dw (optional) = d flevel / d uv_da. */
-static void mip_level(const TexCfg* t, const float* uv_da, const float* bias, size_t pidx,
-                      int* level0, int* level1, float* flevel_out, float dw[4])
+/* ---- cube maps ---------------------------------------------------------------------------- */
+
+/* Face f: major axis ma (sign msgn), s = ss * v[sa] / (2|c|) + 1/2, t = ts * v[ta] / (2|c|) + 1/2.
+ * Faces +x -x +y -y +z -z as in texture_kernel.cu:87-110. */
+typedef struct { int ma, msgn, sa, ss, ta, ts; } CubeFace;
+static const CubeFace kFace[6] = {
+    {0, +1, 2, -1, 1, -1}, {0, -1, 2, +1, 1, -1},
+    {1, +1, 0, +1, 2, +1}, {1, -1, 0, +1, 2, -1},
+    {2, +1, 0, +1, 1, -1}, {2, -1, 0, -1, 1, -1},
+};
+
+static int cube_face_of(const float v[3])
+{
+    float ax = fabsf(v[0]), ay = fabsf(v[1]), az = fabsf(v[2]);
+    int f;
+    if (az > fmaxf(ax, ay)) f = 4; else if (ay > ax) f = 2; else f = 0;
+    if (v[kFace[f].ma] < 0.f) f += 1;
+    return f;
+}
+
+/* texture_kernel.cu:87-110: (s,t) in [0,1] and the face, or -1 for an invalid direction. */
+static int cube_index(const float v[3], float* s, float* t)
+{
+    int f = cube_face_of(v);
+    const CubeFace* F = &kFace[f];
+    float m = (1.f / fabsf(v[F->ma])) * .5f;
+    float x = fmaf(v[F->sa], (float)F->ss * m, .5f);
+    float y = fmaf(v[F->ta], (float)F->ts * m, .5f);
+    if (!isfinite(x) || !isfinite(y)) return -1;
+    *s = fminf(fmaxf(x, 0.f), 1.f);
+    *t = fminf(fmaxf(y, 0.f), 1.f);
+    return f;
+}
+
+/* Texel (ix,iy) of face f at size w, possibly one step outside the face, -> linear texel index
+ * x + w*(y + w*face) on the face it really belongs to, or -1 for the texel that does not exist at a
+ * cube corner.  Integer geometry in units of half texels: the cube is [-w,w]^3, texel centres sit at
+ * odd coordinates, and a texel beyond an edge folds onto the neighbouring face one half-texel inside it. */
+static int64_t cube_texel(int f, int ix, int iy, int w)
+{
+    int ox = (ix < 0 || ix >= w), oy = (iy < 0 || iy >= w);
+    if (ox && oy) return -1;
+    if (!ox && !oy) return (int64_t)ix + (int64_t)w * (iy + (int64_t)w * f);
+    const CubeFace* F = &kFace[f];
+    int p[3];
+    p[F->ma] = F->msgn * w;
+    p[F->sa] = F->ss * (2 * ix + 1 - w);
+    p[F->ta] = F->ts * (2 * iy + 1 - w);
+    int oa = ox ? F->sa : F->ta;                       /* axis along which we left the face */
+    int nsgn = p[oa] > 0 ? 1 : -1;
+    p[oa] = nsgn * w;                                  /* new major axis */
+    p[F->ma] = F->msgn * (w - 1);                      /* one half-texel inside the new face */
+    int nf = oa * 2 + (nsgn < 0 ? 1 : 0);
+    const CubeFace* G = &kFace[nf];
+    int x = (G->ss * p[G->sa] + w - 1) / 2, y = (G->ts * p[G->ta] + w - 1) / 2;
+    return (int64_t)x + (int64_t)w * (y + (int64_t)w * nf);
+}
+
+/* Bilinear footprint on a cube level (texture_kernel.cu:382-434): no clamp, no wrap; *corner is set
+ * when one of the four texels is the missing corner texel.  Returns 0 for an invalid direction. */
+static int index_linear_cube(const TexCfg* t, const float v3[3], int tz, int level, int64_t tc[4], float* fu, float* fv, int* corner)
+{
+    int w = level_dim(t->tex_w, level);
+    float s, tt;
+    int f = cube_index(v3, &s, &tt);
+    *corner = 0;
+    if (f < 0) { tc[0] = tc[1] = tc[2] = tc[3] = -1; *fu = 0.f; *fv = 0.f; return 0; }
+    float u = fmaf(s, (float)w, -0.5f), v = fmaf(tt, (float)w, -0.5f);
+    int iu0 = (int)floorf(u), iv0 = (int)floorf(v);
+    int iu1 = iu0 + 1, iv1 = iv0 + 1;
+    *fu = u - (float)iu0; *fv = v - (float)iv0;
+    int64_t base = (int64_t)6 * tz * w * w;
+    int xs[4] = {iu0, iu1, iu0, iu1}, ys[4] = {iv0, iv0, iv1, iv1};
+    for (int k = 0; k < 4; k++) {
+        int64_t c = cube_texel(f, xs[k], ys[k], w);
+        tc[k] = c < 0 ? -1 : base + c;
+        if (c < 0) *corner = 1;
+    }
+    return 1;
+}
+
+/* dA/d(s,t) -> dA/d(x,y,z) (texture_kernel.cu:113-140). */
+static void cube_grad(const float v[3], float gu, float gv, float g[3])
+{
+    const CubeFace* F = &kFace[cube_face_of(v)];
+    float c = v[F->ma];
+    float m = 1.f / fabsf(c), h = m * .5f;
+    float su = (float)F->ss * gu, sv = (float)F->ts * gv;
+    float sg = (c < 0.f) ? 1.f : -1.f;                                     /* -sign(c) */
+    g[F->sa] = su * h;
+    g[F->ta] = sv * h;
+    g[F->ma] = sg * (su * v[F->sa] + sv * v[F->ta]) * m * h;
+    if (!isfinite(g[0]) || !isfinite(g[1]) || !isfinite(g[2])) g[0] = g[1] = g[2] = 0.f;
+}
+
+/* d(x,y,z)/d(X,Y) -> (ds/dX, ds/dY, dt/dX, dt/dY) (texture_kernel.cu:184-233). */
+static void cube_grad_st(const float v[3], const float dX[3], const float dY[3], float r[4])
+{
+    const CubeFace* F = &kFace[cube_face_of(v)];
+    float c = v[F->ma];
+    float m = 1.f / fabsf(c), h = m * .5f;
+    float k = ((c < 0.f) ? -1.f : 1.f) * m * h;                            /* sign(c) / (2 c^2) */
+    float ss = (float)F->ss, ts = (float)F->ts, a = v[F->sa], b = v[F->ta];
+    r[0] = ss * (h * dX[F->sa] - k * a * dX[F->ma]);
+    r[1] = ss * (h * dY[F->sa] - k * a * dY[F->ma]);
+    r[2] = ts * (h * dX[F->ta] - k * b * dX[F->ma]);
+    r[3] = ts * (h * dY[F->ta] - k * b * dY[F->ma]);
+    if (!finite4(r)) r[0] = r[1] = r[2] = r[3] = 0.f;
+}
+
+/* d(ds/dX, ds/dY, dt/dX, dt/dY)/d(x,y,z): J[axis][component] (texture_kernel.cu:235-317). */
+static void cube_grad2(const float v[3], const float dX[3], const float dY[3], float J[3][4])
+{
+    const CubeFace* F = &kFace[cube_face_of(v)];
+    float c = v[F->ma];
+    float m = 1.f / fabsf(c), h = m * .5f;
+    float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
+    float k2 = 2.f * k / c;                                                /* -dk/dc */
+    float ss = (float)F->ss, ts = (float)F->ts, a = v[F->sa], b = v[F->ta];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) J[i][j] = 0.f;
+    /* d/da of the s components, d/db of the t components */
+    J[F->sa][0] = -ss * k * dX[F->ma];  J[F->sa][1] = -ss * k * dY[F->ma];
+    J[F->ta][2] = -ts * k * dX[F->ma];  J[F->ta][3] = -ts * k * dY[F->ma];
+    /* d/dc */
+    J[F->ma][0] = ss * (-k * dX[F->sa] + k2 * a * dX[F->ma]);
+    J[F->ma][1] = ss * (-k * dY[F->sa] + k2 * a * dY[F->ma]);
+    J[F->ma][2] = ts * (-k * dX[F->ta] + k2 * b * dX[F->ma]);
+    J[F->ma][3] = ts * (-k * dY[F->ta] + k2 * b * dY[F->ma]);
+}
+
+/* dL/d(ds/dX, ds/dY, dt/dX, dt/dY) -> dL/d(d(x,y,z)/dX), dL/d(d(x,y,z)/dY) (texture_kernel.cu:142-182). */
+static void cube_grad4(const float v[3], const float dw[4], float g0[3], float g1[3])
+{
+    const CubeFace* F = &kFace[cube_face_of(v)];
+    float c = v[F->ma];
+    float m = 1.f / fabsf(c), h = m * .5f;
+    float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
+    float ss = (float)F->ss, ts = (float)F->ts, a = v[F->sa], b = v[F->ta];
+    g0[F->sa] = dw[0] * ss * h;  g0[F->ta] = dw[2] * ts * h;  g0[F->ma] = -k * (dw[0] * ss * a + dw[2] * ts * b);
+    g1[F->sa] = dw[1] * ss * h;  g1[F->ta] = dw[3] * ts * h;  g1[F->ma] = -k * (dw[1] * ss * a + dw[3] * ts * b);
+    int ok = isfinite(g0[0]) && isfinite(g0[1]) && isfinite(g0[2]) && isfinite(g1[0]) && isfinite(g1[1]) && isfinite(g1[2]);
+    if (!ok) { g0[0] = g0[1] = g0[2] = 0.f; g1[0] = g1[1] = g1[2] = 0.f; }
+}
+
+/* texture_kernel.cu:477-585.  dw (optional) = d flevel / d(ds/dX, ds/dY, dt/dX, dt/dY); dfdv (cube only)
+ * = d flevel / d(x,y,z) through the direction-dependent face mapping. */
+static void mip_level(const TexCfg* t, const float* uv3, const float* uv_da, const float* bias, size_t pidx,
+                      int* level0, int* level1, float* flevel_out, float dw[4], float dfdv[3])
 {
     float flevel = 0.f;
+    int cube = (t->boundary == B_CUBE);
     *level0 = 0; *level1 = 0;
     if (uv_da) {
-        const float* d = uv_da + pidx * 4;
+        float d[4];
+        float dvdX[3] = {0.f, 0.f, 0.f}, dvdY[3] = {0.f, 0.f, 0.f};
+        if (cube) {
+            const float* q = uv_da + pidx * 6;
+            dvdX[0] = q[0]; dvdY[0] = q[1]; dvdX[1] = q[2]; dvdY[1] = q[3]; dvdX[2] = q[4]; dvdY[2] = q[5];
+            cube_grad_st(uv3, dvdX, dvdY, d);
+        } else {
+            for (int i = 0; i < 4; i++) d[i] = uv_da[pidx * 4 + i];
+        }
         float uscl = (float)t->tex_w, vscl = (float)t->tex_h;
         float dsdx = d[0] * uscl, dsdy = d[1] * uscl, dtdx = d[2] * vscl, dtdy = d[3] * vscl;
         float A = dsdx * dsdx + dtdx * dtdx;
@@ -172,6 +331,13 @@ static void mip_level(const TexCfg* t, const float* uv_da, const float* bias, si
             g[2] = vscl * (dtdx * (l2aw + AB) + dtdy * Cw);
             g[3] = vscl * (dtdy * (l2aw - AB) + dtdx * Cw);
             int ok = finite4(g);
+            if (cube) {
+                float J[3][4], fv[3];
+                cube_grad2(uv3, dvdX, dvdY, J);
+                for (int ax = 0; ax < 3; ax++) fv[ax] = ((J[ax][0] * g[0] + J[ax][1] * g[1]) + J[ax][2] * g[2]) + J[ax][3] * g[3];
+                ok = ok && isfinite(fv[0]) && isfinite(fv[1]) && isfinite(fv[2]);
+                for (int ax = 0; ax < 3; ax++) dfdv[ax] = ok ? fv[ax] : 0.f;
+            }
             for (int i = 0; i < 4; i++) dw[i] = ok ? g[i] : 0.f;
         }
         flevel = .5f * log2f(lenMajorSqr);           /* reference: __log2f; may be inf/NaN, the clamp fixes it */
@@ -188,18 +354,57 @@ static void mip_level(const TexCfg* t, const float* uv_da, const float* bias, si
 
 static float lerpf(float a, float b, float c) { return a + c * (b - a); }
 static float bilerpf(float a, float b, float c, float d, float fu, float fv) { return lerpf(lerpf(a, b, fu), lerpf(c, d, fu), fv); }
-static float texel(const float* p, int64_t tc, int C, int c) { return tc >= 0 ? p[tc * C + c] : 0.f; }
+
+/* texture_kernel.cu:590-614: the four texels of channel c; at a cube corner the missing texel takes
+ * the average of the other three. */
+static void fetch_quad(const float* p, const int64_t tc[4], int corner, int C, int c, float a[4])
+{
+    float sum = 0.f;
+    for (int k = 0; k < 4; k++) { a[k] = tc[k] >= 0 ? p[tc[k] * C + c] : 0.f; if (corner && tc[k] >= 0) sum += a[k]; }
+    if (corner) { float avg = sum * 0.33333333f; for (int k = 0; k < 4; k++) if (tc[k] < 0) a[k] = avg; }
+}
+
+/* texture_kernel.cu:616-639: scatter of the four weights; at a cube corner the missing texel's weight
+ * is shared by the other three. */
+static void accum_quad(double* acc, const int64_t tc[4], int corner, int C, int c, const float wgt[4])
+{
+    float cb = 0.f;
+    if (corner) { for (int k = 0; k < 4; k++) if (tc[k] < 0) cb = wgt[k]; cb *= 0.33333333f; }
+    for (int k = 0; k < 4; k++) if (tc[k] >= 0) acc[tc[k] * C + c] += (double)(corner ? wgt[k] + cb : wgt[k]);
+}
 
 static int check_cfg(TexCfg* t, int L, int tex_n, int tex_h, int tex_w, int C, int filter, int boundary)
 {
-    if (boundary == B_CUBE) return -2;
     if (filter < 0 || filter > 3 || boundary < 0 || boundary > 3) return -1;
+    if (boundary == B_CUBE && tex_h != tex_w) return -1;
     t->tex_n = tex_n; t->tex_h = tex_h; t->tex_w = tex_w; t->C = C; t->filter = filter; t->boundary = boundary;
     t->level_max = (filter == F_LMN || filter == F_LML) ? L : 0;
     return 0;
 }
 
-/* texture_kernel.cu:709-800 */
+/* Footprint of one level in either addressing mode; `ok` = 0 only for an invalid cube direction. */
+static int footprint(const TexCfg* t, const float* uvp, int tz, int level, int64_t tc[4], float* fu, float* fv, int* corner)
+{
+    if (t->boundary == B_CUBE) return index_linear_cube(t, uvp, tz, level, tc, fu, fv, corner);
+    *corner = 0;
+    index_linear(t, uvp[0], uvp[1], tz, level, tc, fu, fv);
+    return 1;
+}
+
+static int64_t nearest_texel(const TexCfg* t, const float* uvp, int tz)
+{
+    if (t->boundary != B_CUBE) return index_nearest(t, uvp[0], uvp[1], tz);
+    float s, tt;
+    int f = cube_index(uvp, &s, &tt);               /* :331-338: no wrap, face folded into tz */
+    if (f < 0) return -1;
+    int w = t->tex_w;
+    int iu = (int)floorf(s * (float)w), iv = (int)floorf(tt * (float)w);
+    iu = iu < 0 ? 0 : (iu > w - 1 ? w - 1 : iu);
+    iv = iv < 0 ? 0 : (iv > w - 1 ? w - 1 : iv);
+    return (int64_t)iu + (int64_t)w * (iv + (int64_t)w * (6 * tz + f));
+}
+
+/* texture_kernel.cu:709-800.  uv has 2 components per pixel (3 for cube maps), uv_da 4 (6). */
 int nvdro_texture_fwd(const float* tex, const float* const* mip_ptrs, int L,
                       const float* uv, const float* uv_da, const float* mip_level_bias,
                       int tex_n, int tex_h, int tex_w, int C,
@@ -212,6 +417,7 @@ int nvdro_texture_fwd(const float* tex, const float* const* mip_ptrs, int L,
     lv[0] = tex;
     for (int i = 1; i <= t.level_max; i++) lv[i] = mip_ptrs[i - 1];
     int mips = (filter == F_LMN || filter == F_LML);
+    int uvs = (boundary == B_CUBE) ? 3 : 2;
     size_t HW = (size_t)H * W, P = (size_t)N * HW;
 
 #pragma omp parallel for schedule(static)
@@ -219,26 +425,26 @@ int nvdro_texture_fwd(const float* tex, const float* const* mip_ptrs, int L,
         size_t pidx = (size_t)pi;
         int pz = (int)(pidx / HW);
         int tz = (tex_n == 1) ? 0 : pz;
-        float u = uv[pidx * 2], v = uv[pidx * 2 + 1];
+        const float* uvp = uv + pidx * uvs;
         float* o = out + pidx * C;
         if (filter == F_NEAREST) {
-            int64_t tc = index_nearest(&t, u, v, tz);
-            for (int c = 0; c < C; c++) o[c] = texel(tex, tc, C, c);
+            int64_t tc = nearest_texel(&t, uvp, tz);
+            for (int c = 0; c < C; c++) o[c] = tc >= 0 ? tex[tc * C + c] : 0.f;
             continue;
         }
         int level0 = 0, level1 = 0; float flevel = 0.f;
-        if (mips) mip_level(&t, uv_da, mip_level_bias, pidx, &level0, &level1, &flevel, NULL);
-        int64_t tc0[4], tc1[4]; float fu0, fv0, fu1 = 0.f, fv1 = 0.f;
-        index_linear(&t, u, v, tz, level0, tc0, &fu0, &fv0);
+        if (mips) mip_level(&t, uvp, uv_da, mip_level_bias, pidx, &level0, &level1, &flevel, NULL, NULL);
+        int64_t tc0[4], tc1[4]; float fu0, fv0, fu1 = 0.f, fv1 = 0.f; int corner0 = 0, corner1 = 0;
+        footprint(&t, uvp, tz, level0, tc0, &fu0, &fv0, &corner0);
         int second = (filter == F_LML && flevel > 0.f);
-        if (second) index_linear(&t, u, v, tz, level1, tc1, &fu1, &fv1);
+        if (second) footprint(&t, uvp, tz, level1, tc1, &fu1, &fv1, &corner1);
         for (int c = 0; c < C; c++) {
-            const float* p0 = lv[level0];
-            float a = bilerpf(texel(p0, tc0[0], C, c), texel(p0, tc0[1], C, c), texel(p0, tc0[2], C, c), texel(p0, tc0[3], C, c), fu0, fv0);
+            float q[4];
+            fetch_quad(lv[level0], tc0, corner0, C, c, q);
+            float a = bilerpf(q[0], q[1], q[2], q[3], fu0, fv0);
             if (second) {
-                const float* p1 = lv[level1];
-                float b = bilerpf(texel(p1, tc1[0], C, c), texel(p1, tc1[1], C, c), texel(p1, tc1[2], C, c), texel(p1, tc1[3], C, c), fu1, fv1);
-                a = lerpf(a, b, flevel);
+                fetch_quad(lv[level1], tc1, corner1, C, c, q);
+                a = lerpf(a, bilerpf(q[0], q[1], q[2], q[3], fu1, fv1), flevel);
             }
             o[c] = a;
         }
@@ -261,13 +467,16 @@ int nvdro_texture_grad(const float* tex, const float* const* mip_ptrs, int L,
     int rc = check_cfg(&t, L, tex_n, tex_h, tex_w, C, filter, boundary);
     if (rc) return rc;
     int mips = (filter == F_LMN || filter == F_LML);
+    int cube = (boundary == B_CUBE);
+    int uvs = cube ? 3 : 2, das = cube ? 6 : 4;
+    int slices = cube ? tex_n * 6 : tex_n;
     const float* lv[MAX_LEVELS];
     double* acc[MAX_LEVELS];
     size_t cnt[MAX_LEVELS];
     lv[0] = tex;
     for (int i = 0; i <= t.level_max; i++) {
         if (i > 0) lv[i] = mip_ptrs[i - 1];
-        cnt[i] = (size_t)tex_n * level_dim(tex_h, i) * level_dim(tex_w, i) * C;
+        cnt[i] = (size_t)slices * level_dim(tex_h, i) * level_dim(tex_w, i) * C;
         acc[i] = (double*)calloc(cnt[i], sizeof(double));
         if (!acc[i]) return -3;
     }
@@ -277,83 +486,86 @@ int nvdro_texture_grad(const float* tex, const float* const* mip_ptrs, int L,
         int pz = (int)(pidx / HW);
         int tz = (tex_n == 1) ? 0 : pz;
         const float* pdy = dy + pidx * C;
+        const float* uvp = uv + pidx * uvs;
         uint32_t dmax = 0;
         for (int c = 0; c < C; c++) { uint32_t b; memcpy(&b, &pdy[c], 4); dmax |= b; }
         float dm; memcpy(&dm, &dmax, 4);
         if (dm == 0.f) {                                            /* :922-971 */
-            if (filter != F_NEAREST && g_uv) { g_uv[pidx * 2] = 0.f; g_uv[pidx * 2 + 1] = 0.f; }
+            if (filter != F_NEAREST && g_uv) for (int i = 0; i < uvs; i++) g_uv[pidx * uvs + i] = 0.f;
             if (filter == F_LML) {
-                if (g_uv_da) for (int i = 0; i < 4; i++) g_uv_da[pidx * 4 + i] = 0.f;
+                if (g_uv_da) for (int i = 0; i < das; i++) g_uv_da[pidx * das + i] = 0.f;
                 if (g_mip_level_bias) g_mip_level_bias[pidx] = 0.f;
             }
             continue;
         }
-        float u = uv[pidx * 2], v = uv[pidx * 2 + 1];
         if (filter == F_NEAREST) {
-            int64_t tc = index_nearest(&t, u, v, tz);
+            int64_t tc = nearest_texel(&t, uvp, tz);
             if (tc >= 0) for (int c = 0; c < C; c++) acc[0][tc * C + c] += (double)pdy[c];
             continue;
         }
         int level0 = 0, level1 = 0; float flevel = 0.f;
-        float dw[4] = {0.f, 0.f, 0.f, 0.f};
-        if (mips) mip_level(&t, uv_da, mip_level_bias, pidx, &level0, &level1, &flevel, dw);
-        int64_t tc0[4], tc1[4]; float fu0, fv0, fu1 = 0.f, fv1 = 0.f;
-        index_linear(&t, u, v, tz, level0, tc0, &fu0, &fv0);
+        float dw[4] = {0.f, 0.f, 0.f, 0.f}, dfdv[3] = {0.f, 0.f, 0.f};
+        if (mips) mip_level(&t, uvp, uv_da, mip_level_bias, pidx, &level0, &level1, &flevel, dw, dfdv);
+        int64_t tc0[4], tc1[4]; float fu0, fv0, fu1 = 0.f, fv1 = 0.f; int corner0 = 0, corner1 = 0;
+        footprint(&t, uvp, tz, level0, tc0, &fu0, &fv0, &corner0);
         float w011 = fu0 * fv0, w010 = fu0 - w011, w001 = fv0 - w011, w000 = 1.f - fu0 - w001;
         float tw0[4] = {w000, w010, w001, w011};
         float sclu0 = (float)level_dim(tex_w, level0), sclv0 = (float)level_dim(tex_h, level0);
         float gu = 0.f, gv = 0.f, df = 0.f;
-
-        if (filter == F_LINEAR || filter == F_LMN) {
-            for (int c = 0; c < C; c++) {
-                float d = pdy[c];
-                for (int k = 0; k < 4; k++) if (tc0[k] >= 0) acc[level0][tc0[k] * C + c] += (double)(tw0[k] * d);
-                const float* p0 = lv[level0];
-                float a00 = texel(p0, tc0[0], C, c), a10 = texel(p0, tc0[1], C, c), a01 = texel(p0, tc0[2], C, c), a11 = texel(p0, tc0[3], C, c);
-                float ad = (a11 + a00 - a10 - a01);
-                gu += d * ((a10 - a00) + fv0 * ad) * sclu0;
-                gv += d * ((a01 - a00) + fu0 * ad) * sclv0;
-            }
-            if (g_uv) { g_uv[pidx * 2] = gu; g_uv[pidx * 2 + 1] = gv; }
-            continue;
+        int trilinear = (filter == F_LML);
+        float tw1[4] = {0.f, 0.f, 0.f, 0.f}, sclu1 = 0.f, sclv1 = 0.f;
+        if (trilinear) {
+            footprint(&t, uvp, tz, level1, tc1, &fu1, &fv1, &corner1);
+            float w111 = fu1 * fv1, w110 = fu1 - w111, w101 = fv1 - w111, w100 = 1.f - fu1 - w101;
+            tw1[0] = w100; tw1[1] = w110; tw1[2] = w101; tw1[3] = w111;
+            sclu1 = (float)level_dim(tex_w, level1); sclv1 = (float)level_dim(tex_h, level1);
         }
-
-        /* trilinear */
-        index_linear(&t, u, v, tz, level1, tc1, &fu1, &fv1);
-        float w111 = fu1 * fv1, w110 = fu1 - w111, w101 = fv1 - w111, w100 = 1.f - fu1 - w101;
-        float tw1[4] = {w100, w110, w101, w111};
-        float sclu1 = (float)level_dim(tex_w, level1), sclv1 = (float)level_dim(tex_h, level1);
         for (int c = 0; c < C; c++) {
             float d = pdy[c];
-            float d0 = (1.f - flevel) * d;
-            for (int k = 0; k < 4; k++) if (tc0[k] >= 0) acc[level0][tc0[k] * C + c] += (double)(tw0[k] * d0);
-            const float* p0 = lv[level0];
-            float a00 = texel(p0, tc0[0], C, c), a10 = texel(p0, tc0[1], C, c), a01 = texel(p0, tc0[2], C, c), a11 = texel(p0, tc0[3], C, c);
-            float ad = (a11 + a00 - a10 - a01);
-            gu += d0 * ((a10 - a00) + fv0 * ad) * sclu0;
-            gv += d0 * ((a01 - a00) + fu0 * ad) * sclv0;
-            if (flevel > 0.f) {
+            float d0 = trilinear ? (1.f - flevel) * d : d;
+            float wq[4] = {tw0[0] * d0, tw0[1] * d0, tw0[2] * d0, tw0[3] * d0};
+            accum_quad(acc[level0], tc0, corner0, C, c, wq);
+            float a[4];
+            fetch_quad(lv[level0], tc0, corner0, C, c, a);
+            float ad = (a[3] + a[0] - a[1] - a[2]);
+            gu += d0 * ((a[1] - a[0]) + fv0 * ad) * sclu0;
+            gv += d0 * ((a[2] - a[0]) + fu0 * ad) * sclv0;
+            if (trilinear && flevel > 0.f) {
                 float d1 = flevel * d;
-                for (int k = 0; k < 4; k++) if (tc1[k] >= 0) acc[level1][tc1[k] * C + c] += (double)(tw1[k] * d1);
-                const float* p1 = lv[level1];
-                float b00 = texel(p1, tc1[0], C, c), b10 = texel(p1, tc1[1], C, c), b01 = texel(p1, tc1[2], C, c), b11 = texel(p1, tc1[3], C, c);
-                float bd = (b11 + b00 - b10 - b01);
-                gu += d1 * ((b10 - b00) + fv1 * bd) * sclu1;
-                gv += d1 * ((b01 - b00) + fu1 * bd) * sclv1;
-                float a = bilerpf(a00, a10, a01, a11, fu0, fv0);
-                float b = bilerpf(b00, b10, b01, b11, fu1, fv1);
-                df += (b - a) * d;
+                float wq1[4] = {tw1[0] * d1, tw1[1] * d1, tw1[2] * d1, tw1[3] * d1};
+                accum_quad(acc[level1], tc1, corner1, C, c, wq1);
+                float b[4];
+                fetch_quad(lv[level1], tc1, corner1, C, c, b);
+                float bd = (b[3] + b[0] - b[1] - b[2]);
+                gu += d1 * ((b[1] - b[0]) + fv1 * bd) * sclu1;
+                gv += d1 * ((b[2] - b[0]) + fu1 * bd) * sclv1;
+                df += (bilerpf(b[0], b[1], b[2], b[3], fu1, fv1) - bilerpf(a[0], a[1], a[2], a[3], fu0, fv0)) * d;
             }
         }
-        if (g_uv) { g_uv[pidx * 2] = gu; g_uv[pidx * 2 + 1] = gv; }
-        if (g_mip_level_bias) g_mip_level_bias[pidx] = df;
-        if (uv_da && g_uv_da) for (int i = 0; i < 4; i++) g_uv_da[pidx * 4 + i] = dw[i] * df;
+        if (g_uv) {
+            if (cube) {
+                float g3[3];
+                cube_grad(uvp, gu, gv, g3);
+                for (int i = 0; i < 3; i++) g_uv[pidx * 3 + i] = trilinear ? g3[i] + dfdv[i] * df : g3[i];
+            } else { g_uv[pidx * 2] = gu; g_uv[pidx * 2 + 1] = gv; }
+        }
+        if (trilinear) {
+            if (g_mip_level_bias) g_mip_level_bias[pidx] = df;
+            if (uv_da && g_uv_da) {
+                float dwf[4] = {dw[0] * df, dw[1] * df, dw[2] * df, dw[3] * df};
+                if (cube) {
+                    float g0[3], g1[3];
+                    cube_grad4(uvp, dwf, g0, g1);
+                    for (int i = 0; i < 3; i++) { g_uv_da[pidx * 6 + 2 * i] = g0[i]; g_uv_da[pidx * 6 + 2 * i + 1] = g1[i]; }
+                } else for (int i = 0; i < 4; i++) g_uv_da[pidx * 4 + i] = dwf[i];
+            }
+        }
     }
 
     /* MipGradKernel (:843-895): every base texel pulls its ancestors' gradients, weight 1/4 per
      * level (1/2 when the level below had an extent of 1). */
     if (pull_mip_grads && t.level_max > 0) {
-        for (int z = 0; z < tex_n; z++)
+        for (int z = 0; z < slices; z++)
         for (int y = 0; y < tex_h; y++)
         for (int x = 0; x < tex_w; x++) {
             int xx = x, yy = y; double wgt = 1.0;
@@ -375,3 +587,7 @@ int nvdro_texture_grad(const float* tex, const float* const* mip_ptrs, int L,
     for (int i = 0; i <= t.level_max; i++) free(acc[i]);
     return 0;
 }
+
+/* Test hooks for the cube-map helpers (tests/test_oracle_texture_aa.py). */
+long long nvdro_cube_texel(int face, int ix, int iy, int w) { return (long long)cube_texel(face, ix, iy, w); }
+int nvdro_cube_index(const float* v, float* s, float* t) { return cube_index(v, s, t); }

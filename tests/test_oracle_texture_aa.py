@@ -218,3 +218,153 @@ def test_antialias_gradients(oracle):
         assert np.abs(gp[0, :, :2] - exp).max() < 0.08 * np.abs(exp).max()
         # w-gradient of a vertex = -(x, y) . (gx, gy) / w  (antialias.cu:531-532) with w = 1 here
         assert np.allclose(gp[0, :, 3], -(pos[0, :, 0] * gp[0, :, 0] + pos[0, :, 1] * gp[0, :, 1]), rtol=1e-3, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------ cube maps
+
+# OpenGL cube-map convention (what texture_kernel.cu:87-110 implements): face -> (major axis, sign,
+# s axis, s sign, t axis, t sign), stated here independently of the oracle's table.
+_GL_FACES = [(0, +1, 2, -1, 1, -1), (0, -1, 2, +1, 1, -1), (1, +1, 0, +1, 2, +1),
+             (1, -1, 0, +1, 2, -1), (2, +1, 0, +1, 1, -1), (2, -1, 0, -1, 1, -1)]
+
+
+def _texel_center(face, ix, iy, w):
+    """3D position of a texel centre on the cube [-1,1]^3 (also defined one texel outside the face)."""
+    ma, ms, sa, ss, ta, ts = _GL_FACES[face]
+    p = np.zeros(3)
+    p[ma] = ms
+    p[sa] = ss * ((2 * ix + 1) / w - 1.0)
+    p[ta] = ts * ((2 * iy + 1) / w - 1.0)
+    return p
+
+
+def test_cube_face_lookup_and_edge_fold(oracle):
+    import ctypes
+    lib = oracle.lib()
+    lib.nvdro_cube_texel.restype = ctypes.c_longlong
+    rng = np.random.default_rng(11)
+    # face lookup agrees with the GL table
+    for _ in range(200):
+        v = rng.normal(size=3).astype(np.float32)
+        s = ctypes.c_float(); t = ctypes.c_float()
+        f = lib.nvdro_cube_index(v.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(s), ctypes.byref(t))
+        ma, ms, sa, ss, ta, ts = _GL_FACES[f]
+        assert ma == int(np.argmax(np.abs(v))) and ms == np.sign(v[ma])
+        assert np.isclose(s.value, 0.5 * ss * v[sa] / abs(v[ma]) + 0.5, atol=1e-6)
+        assert np.isclose(t.value, 0.5 * ts * v[ta] / abs(v[ma]) + 0.5, atol=1e-6)
+    zero = np.zeros(3, np.float32)
+    assert lib.nvdro_cube_index(zero.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), ctypes.byref(s), ctypes.byref(t)) == -1
+    # a texel one step beyond an edge folds onto the real texel nearest to where it would have been
+    for w in (1, 2, 4, 5):
+        centers = {(f, x, y): _texel_center(f, x, y, w) for f in range(6) for x in range(w) for y in range(w)}
+        for f in range(6):
+            for i in range(w):
+                for (ix, iy) in ((-1, i), (w, i), (i, -1), (i, w)):
+                    got = lib.nvdro_cube_texel(f, ix, iy, w)
+                    virt = _texel_center(f, ix, iy, w)
+                    best = min((k for k in centers if k[0] != f), key=lambda k: np.sum((centers[k] - virt) ** 2))
+                    assert got == best[1] + w * (best[2] + w * best[0]), (w, f, ix, iy)
+            for (ix, iy) in ((-1, -1), (w, -1), (-1, w), (w, w)):
+                assert lib.nvdro_cube_texel(f, ix, iy, w) == -1           # no fourth texel at a corner
+            assert lib.nvdro_cube_texel(f, 0, w - 1, w) == 0 + w * (w - 1 + w * f)
+
+
+def _dir_texture(rng, S, C):
+    return rng.uniform(size=(1, 6, S, S, C)).astype(np.float32)
+
+
+def test_cube_sampling_is_seamless_and_corner_aware(oracle):
+    # A texture that is a linear function of the texel centre's 3D position is reproduced (to O(1/S))
+    # everywhere, including across edges and at corners, only if every fold picks the right neighbour.
+    S = 16
+    alpha = np.array([0.3, -0.5, 0.8])
+    tex = np.zeros((1, 6, S, S, 1), np.float32)
+    for f in range(6):
+        for y in range(S):
+            for x in range(S):
+                tex[0, f, y, x, 0] = alpha @ _texel_center(f, x, y, S)
+    rng = np.random.default_rng(12)
+    v = rng.normal(size=(1, 40, 40, 3)).astype(np.float32)
+    # add directions hugging edges and corners
+    v[0, 0, :, :] = np.array([1, 1, 0]) + rng.normal(size=(40, 3)) * 0.02
+    v[0, 1, :, :] = np.array([1, -1, 1]) + rng.normal(size=(40, 3)) * 0.02
+    v[0, 2, :, :] = np.array([-1, -1, -1]) + rng.normal(size=(40, 3)) * 0.02
+    o = oracle.texture(tex, v, filter_mode="linear", boundary_mode="cube")[..., 0]
+    p = v / np.abs(v).max(-1, keepdims=True)                      # point on the cube surface
+    assert np.abs(o - p @ alpha).max() < 2.5 * np.abs(alpha).sum() / S
+    # nearest: a texture holding the face index returns the face of the direction
+    texf = np.zeros((1, 6, 4, 4, 1), np.float32)
+    for f in range(6):
+        texf[0, f] = f
+    of = oracle.texture(texf, v, filter_mode="nearest", boundary_mode="cube")[..., 0]
+    ma = np.abs(v).argmax(-1)
+    expect = 2 * ma + (np.take_along_axis(v, ma[..., None], -1)[..., 0] < 0)
+    assert np.array_equal(of, expect.astype(np.float32))
+    # invalid direction -> zeros, no gradient
+    z = np.zeros((1, 1, 1, 3), np.float32)
+    assert oracle.texture(tex, z, filter_mode="linear", boundary_mode="cube").sum() == 0.0
+
+
+@pytest.mark.parametrize("fm", ["nearest", "linear", "linear-mipmap-nearest", "linear-mipmap-linear"])
+def test_cube_gradients(oracle, fm):
+    rng = np.random.default_rng(13)
+    S, C = 8, 2
+    tex = _dir_texture(rng, S, C)
+    v = rng.normal(size=(2, 7, 7, 3)).astype(np.float32)
+    v[0, 0] = np.array([1, 0.97, 0.2]) + rng.normal(size=(7, 3)) * 0.05        # near an edge
+    v[0, 1] = np.array([1, -1, 1]) + rng.normal(size=(7, 3)) * 0.04            # near a corner
+    v = v.astype(np.float32)
+    mip = "mipmap" in fm
+    da = (rng.normal(size=(2, 7, 7, 6)) * 0.15).astype(np.float32) if mip else None
+    bias = rng.uniform(-0.3, 0.3, size=(2, 7, 7)).astype(np.float32) if mip else None
+    dy = rng.normal(size=(2, 7, 7, C)).astype(np.float32)
+    kw = dict(filter_mode=fm, boundary_mode="cube")
+    f = lambda t=tex, u=v, d=da, b=bias: oracle.texture(t, u, d, b, **kw).astype(np.float64)
+    g = oracle.texture_grad(tex, v, dy, da, bias, **kw)
+    e = rng.normal(size=tex.shape).astype(np.float32)
+    assert np.isclose(((f(t=tex + e) - f()) * dy).sum(), (g["tex"].astype(np.float64) * e).sum(), rtol=3e-4, atol=3e-4)
+    if fm == "nearest":
+        return
+    assert g["uv"].shape == v.shape
+    eps = 1e-3
+    fd = np.zeros(v.shape, np.float64)
+    for k in range(3):
+        up = v.copy(); up[..., k] += eps
+        um = v.copy(); um[..., k] -= eps
+        fd[..., k] = ((f(u=up) - f(u=um)) * dy).sum(-1) / (2 * eps)
+    err = np.abs(fd - g["uv"])
+    scale = max(1.0, np.abs(fd).max())
+    assert np.median(err) < 2e-2 * scale and (err < 6e-2 * scale).mean() > 0.75
+    if fm == "linear-mipmap-linear":
+        assert g["uv_da"].shape == da.shape
+        fda = np.zeros(da.shape, np.float64)
+        for k in range(6):
+            dp = da.copy(); dp[..., k] += 1e-4
+            dm = da.copy(); dm[..., k] -= 1e-4
+            fda[..., k] = ((f(d=dp) - f(d=dm)) * dy).sum(-1) / 2e-4
+        erra = np.abs(fda - g["uv_da"])
+        assert (erra < 4e-2 * max(1.0, np.abs(fda).max())).mean() > 0.8
+        fdb = ((f(b=bias + eps) - f(b=bias - eps)) * dy).sum(-1) / (2 * eps)
+        assert (np.abs(fdb - g["mip_level_bias"]) < 2e-2 * max(1.0, np.abs(fdb).max())).mean() > 0.8
+
+
+def test_cube_mip_level_gradient_wrt_direction(oracle):
+    # With a texture whose level-k mip is the constant k the output IS the mip level, so g_uv is purely
+    # d(level)/d(direction): checks the second-derivative path (texture_kernel.cu:235-317).
+    S = 32
+    tex = np.zeros((1, 6, S, S, 1), np.float32)
+    levels = [np.full((1, 6, S >> k, S >> k, 1), float(k), np.float32) for k in range(1, 6)]
+    rng = np.random.default_rng(14)
+    v = (rng.normal(size=(1, 6, 6, 3)) + np.array([0.2, 0.1, 1.5])).astype(np.float32)
+    da = (rng.normal(size=(1, 6, 6, 6)) * 0.3).astype(np.float32)
+    kw = dict(mip=levels, filter_mode="linear-mipmap-linear", boundary_mode="cube")
+    f = lambda u: oracle.texture(tex, u, da, **kw).astype(np.float64)[..., 0]
+    lvl = f(v)
+    assert lvl.min() > 0.02 and lvl.max() < 4.98                  # away from the clamps
+    g = oracle.texture_grad(tex, v, np.ones((1, 6, 6, 1), np.float32), da, **kw)
+    eps = 1e-3
+    for k in range(3):
+        up = v.copy(); up[..., k] += eps
+        um = v.copy(); um[..., k] -= eps
+        fd = (f(up) - f(um)) / (2 * eps)
+        assert np.abs(fd - g["uv"][..., k]).max() < 2e-2 * max(1.0, np.abs(fd).max())
