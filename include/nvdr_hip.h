@@ -96,10 +96,12 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
 /* ---- texture --------------------------------------------------------------------
  * Replaces texture_construct_mip / texture_fwd / texture_fwd_mip / texture_grad_nearest /
  * texture_grad_linear / texture_grad_linear_mipmap_nearest / texture_grad_linear_mipmap_linear
- * (torch_bindings.cpp:61-67; csrc/torch/torch_texture.cpp:98-716) for 2D textures.
+ * (torch_bindings.cpp:61-67; csrc/torch/torch_texture.cpp:98-716).
  * filter_mode: 0 nearest, 1 linear, 2 linear-mipmap-nearest, 3 linear-mipmap-linear;
- * boundary_mode: 0 cube (rejected: not implemented), 1 wrap, 2 clamp, 3 zero (ops.py:415-420).
- * tex [tex_n,tex_h,tex_w,C] with tex_n == N or 1; uv [N,H,W,2]; uv_da [N,H,W,4] or NULL;
+ * boundary_mode: 0 cube, 1 wrap, 2 clamp, 3 zero (ops.py:415-420).
+ * 2D: tex [tex_n,tex_h,tex_w,C] with tex_n == N or 1; uv [N,H,W,2]; uv_da [N,H,W,4] or NULL.
+ * Cube (boundary_mode 0): tex [tex_n,6,S,S,C] passed as tex_h = tex_w = S; uv [N,H,W,3] direction
+ * vectors; uv_da [N,H,W,6] = (dx/dX, dx/dY, dy/dX, dy/dY, dz/dX, dz/dY) or NULL.
  * mip_level_bias [N,H,W] or NULL; out / dy [N,H,W,C]. */
 
 /* Mip geometry (pure host code; csrc/common/texture.cpp:62-102): fills widths / heights /

@@ -1,7 +1,7 @@
 // texture.hip -- texture sampling forward / backward, mip construction for gfx950.
 //
 // Replaces csrc/common/texture_kernel.cu + csrc/common/texture.cpp + csrc/torch/torch_texture.cpp
-// behind the C ABI (2D textures; cube maps are rejected with a message).
+// behind the C ABI (2D textures and cube maps).
 //
 //  k_mip_build   one lane per output texel, 2x2 box filter (texture_kernel.cu:644-699).
 //  k_tex_fwd     one lane per pixel, a wave = one 8x8 pixel tile so that the 4..8 texel taps of
@@ -47,7 +47,10 @@ __device__ __forceinline__ long long tex_index_nearest(const TexParams& p, float
     return (long long)iu + (long long)w * (iv + (long long)tz * h);
 }
 
-struct Quad { long long tc[4]; float fu, fv; int x0, x1, y0, y1; };   // texel indices x0y0, x1y0, x0y1, x1y1 (or -1), weights, texel coords
+// Bilinear footprint: texel indices of taps x0y0, x1y0, x0y1, x1y1 (-1 = no texel), weights, and each
+// tap's texel column / row inside its slice (cube maps: row = y + w * face).  `corner` marks a cube
+// corner footprint, whose missing texel stands for the average of the other three.
+struct Quad { long long tc[4]; float fu, fv; int tx[4], ty[4]; bool corner; };
 
 // texture_kernel.cu:368-472.  The one explicit fma is where the reference's compiler contracts.
 __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, float v, int tz, int level)
@@ -75,7 +78,9 @@ __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, fl
         if (iu1 >= w) iu1 -= w;
         if (iv1 >= h) iv1 -= h;
     }
-    q.x0 = iu0; q.x1 = iu1; q.y0 = iv0; q.y1 = iv1;
+    q.tx[0] = iu0; q.tx[1] = iu1; q.tx[2] = iu0; q.tx[3] = iu1;
+    q.ty[0] = iv0; q.ty[1] = iv0; q.ty[2] = iv1; q.ty[3] = iv1;
+    q.corner = false;
     const long long base = (long long)tz * w * h;
     q.tc[0] = base + iu0 + (long long)w * iv0;
     q.tc[1] = base + iu1 + (long long)w * iv0;
@@ -94,15 +99,195 @@ __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, fl
 
 __device__ __forceinline__ bool finite4(float4 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z) && isfinite(a.w); }
 
+// ---- cube maps (texture_kernel.cu:31-317) ----------------------------------------------------
+// Stated from the geometry, not from the reference's bit tables: face f has major axis ma (sign
+// msgn) and s = ss * v[sa] / (2|c|) + 1/2, t = ts * v[ta] / (2|c|) + 1/2 (the OpenGL convention the
+// reference implements, :87-110); the gradient helpers are the derivatives of that map and texels
+// beyond a face edge are folded onto the neighbouring face with integer geometry.
+
+struct CubeFace { int ma, msgn, sa, ss, ta, ts; };
+__device__ __forceinline__ CubeFace cube_face(int f)
+{
+    // +x -x +y -y +z -z
+    const int ma = f >> 1;
+    const int msgn = (f & 1) ? -1 : 1;
+    const int sa = (ma == 0) ? 2 : 0;
+    const int ta = (ma == 1) ? 2 : 1;
+    const int ss = (f == 0 || f == 5) ? -1 : 1;
+    const int ts = (f == 2) ? 1 : -1;
+    return CubeFace{ma, msgn, sa, ss, ta, ts};
+}
+
+__device__ __forceinline__ float comp3(float3 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
+__device__ __forceinline__ void set3(float3& v, int i, float x) { if (i == 0) v.x = x; else if (i == 1) v.y = x; else v.z = x; }
+
+__device__ __forceinline__ int compi3(int3 v, int i) { return i == 0 ? v.x : i == 1 ? v.y : v.z; }
+__device__ __forceinline__ void seti3(int3& v, int i, int x) { if (i == 0) v.x = x; else if (i == 1) v.y = x; else v.z = x; }
+
+__device__ __forceinline__ int cube_face_of(float3 v)
+{
+    const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z);
+    int f;
+    if (az > fmaxf(ax, ay)) f = 4; else if (ay > ax) f = 2; else f = 0;
+    if (comp3(v, f >> 1) < 0.f) f += 1;
+    return f;
+}
+
+// (s,t) in [0,1] and the face, or -1 for an invalid direction (:87-110).
+__device__ __forceinline__ int cube_index(float3 v, float& s, float& t)
+{
+#pragma clang fp contract(off)
+    const int f = cube_face_of(v);
+    const CubeFace F = cube_face(f);
+    const float m = (1.f / fabsf(comp3(v, F.ma))) * .5f;
+    const float x = __fmaf_rn(comp3(v, F.sa), (float)F.ss * m, .5f);
+    const float y = __fmaf_rn(comp3(v, F.ta), (float)F.ts * m, .5f);
+    if (!isfinite(x) || !isfinite(y)) return -1;
+    s = fminf(fmaxf(x, 0.f), 1.f);
+    t = fminf(fmaxf(y, 0.f), 1.f);
+    return f;
+}
+
+// Texel (ix,iy) of face f at size w, possibly one step outside the face -> (column, row + w * face) on
+// the face it belongs to; false for the texel that does not exist at a cube corner.  Half-texel integer
+// geometry: cube [-w,w]^3, texel centres at odd coordinates, a texel beyond an edge folds one
+// half-texel inside the neighbouring face.
+__device__ __forceinline__ bool cube_texel(int f, int ix, int iy, int w, int& cx, int& cy)
+{
+    const bool ox = (ix < 0 || ix >= w), oy = (iy < 0 || iy >= w);
+    if (ox && oy) return false;
+    if (!ox && !oy) { cx = ix; cy = iy + w * f; return true; }
+    const CubeFace F = cube_face(f);
+    int3 q = make_int3(0, 0, 0);
+    seti3(q, F.ma, F.msgn * w);
+    seti3(q, F.sa, F.ss * (2 * ix + 1 - w));
+    seti3(q, F.ta, F.ts * (2 * iy + 1 - w));
+    const int oa = ox ? F.sa : F.ta;
+    const int nsgn = compi3(q, oa) > 0 ? 1 : -1;
+    seti3(q, oa, nsgn * w);
+    seti3(q, F.ma, F.msgn * (w - 1));
+    const int nf = oa * 2 + (nsgn < 0 ? 1 : 0);
+    const CubeFace G = cube_face(nf);
+    cx = (G.ss * compi3(q, G.sa) + w - 1) >> 1;
+    cy = ((G.ts * compi3(q, G.ta) + w - 1) >> 1) + w * nf;
+    return true;
+}
+
+// Footprint on a cube level (:382-434): no clamp, no wrap.  All taps -1 for an invalid direction.
+__device__ __forceinline__ Quad tex_index_linear_cube(const TexParams& p, float3 v3, int tz, int level)
+{
+#pragma clang fp contract(off)
+    Quad q;
+    q.corner = false;
+    q.fu = 0.f; q.fv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { q.tc[k] = -1; q.tx[k] = 0; q.ty[k] = 0; }
+    const int w = level_dim(p.texW, level);
+    float s, t;
+    const int f = cube_index(v3, s, t);
+    if (f < 0) return q;
+    const float u = __fmaf_rn(s, (float)w, -0.5f), v = __fmaf_rn(t, (float)w, -0.5f);
+    const int iu0 = __float2int_rd(u), iv0 = __float2int_rd(v);
+    q.fu = u - (float)iu0; q.fv = v - (float)iv0;
+    const long long base = 6ll * tz * w * w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int cx, cy;
+        if (cube_texel(f, iu0 + (k & 1), iv0 + (k >> 1), w, cx, cy)) { q.tx[k] = cx; q.ty[k] = cy; q.tc[k] = base + cx + (long long)w * cy; }
+        else q.corner = true;
+    }
+    return q;
+}
+
+// dA/d(s,t) -> dA/d(x,y,z) (:113-140).
+__device__ __forceinline__ float3 cube_grad(float3 v, float gu, float gv)
+{
+#pragma clang fp contract(off)
+    const CubeFace F = cube_face(cube_face_of(v));
+    const float c = comp3(v, F.ma);
+    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float su = (float)F.ss * gu, sv = (float)F.ts * gv;
+    const float sg = (c < 0.f) ? 1.f : -1.f;
+    float3 g = make_float3(0.f, 0.f, 0.f);
+    set3(g, F.sa, su * h);
+    set3(g, F.ta, sv * h);
+    set3(g, F.ma, sg * (su * comp3(v, F.sa) + sv * comp3(v, F.ta)) * m * h);
+    if (!isfinite(g.x) || !isfinite(g.y) || !isfinite(g.z)) g = make_float3(0.f, 0.f, 0.f);
+    return g;
+}
+
+// d(x,y,z)/d(X,Y) -> (ds/dX, ds/dY, dt/dX, dt/dY) (:184-233).
+__device__ __forceinline__ float4 cube_grad_st(float3 v, float3 dX, float3 dY)
+{
+#pragma clang fp contract(off)
+    const CubeFace F = cube_face(cube_face_of(v));
+    const float c = comp3(v, F.ma);
+    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
+    const float ss = (float)F.ss, ts = (float)F.ts, a = comp3(v, F.sa), b = comp3(v, F.ta);
+    const float4 r = make_float4(ss * (h * comp3(dX, F.sa) - k * a * comp3(dX, F.ma)), ss * (h * comp3(dY, F.sa) - k * a * comp3(dY, F.ma)),
+                                 ts * (h * comp3(dX, F.ta) - k * b * comp3(dX, F.ma)), ts * (h * comp3(dY, F.ta) - k * b * comp3(dY, F.ma)));
+    return finite4(r) ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// sum_j g_j * d(component j of (ds/dX, ds/dY, dt/dX, dt/dY))/d(x,y,z) (:235-317 contracted with g).
+__device__ __forceinline__ float3 cube_grad2_dot(float3 v, float3 dX, float3 dY, float4 g)
+{
+#pragma clang fp contract(off)
+    const CubeFace F = cube_face(cube_face_of(v));
+    const float c = comp3(v, F.ma);
+    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
+    const float k2 = 2.f * k / c;
+    const float ss = (float)F.ss, ts = (float)F.ts, a = comp3(v, F.sa), b = comp3(v, F.ta);
+    const float dXc = comp3(dX, F.ma), dYc = comp3(dY, F.ma);
+    // rows of the Jacobian, in the oracle's summation order ((J0*g0 + J1*g1) + J2*g2) + J3*g3
+    const float ja0 = -ss * k * dXc, ja1 = -ss * k * dYc;
+    const float jb2 = -ts * k * dXc, jb3 = -ts * k * dYc;
+    const float jc0 = ss * (-k * comp3(dX, F.sa) + k2 * a * dXc), jc1 = ss * (-k * comp3(dY, F.sa) + k2 * a * dYc);
+    const float jc2 = ts * (-k * comp3(dX, F.ta) + k2 * b * dXc), jc3 = ts * (-k * comp3(dY, F.ta) + k2 * b * dYc);
+    float3 r = make_float3(0.f, 0.f, 0.f);
+    set3(r, F.sa, ((ja0 * g.x + ja1 * g.y) + 0.f * g.z) + 0.f * g.w);
+    set3(r, F.ta, ((0.f * g.x + 0.f * g.y) + jb2 * g.z) + jb3 * g.w);
+    set3(r, F.ma, ((jc0 * g.x + jc1 * g.y) + jc2 * g.z) + jc3 * g.w);
+    return r;
+}
+
+// dL/d(ds/dX, ds/dY, dt/dX, dt/dY) -> dL/d(d(x,y,z)/dX), dL/d(d(x,y,z)/dY) (:142-182).
+__device__ __forceinline__ void cube_grad4(float3 v, float4 dw, float3& g0, float3& g1)
+{
+#pragma clang fp contract(off)
+    const CubeFace F = cube_face(cube_face_of(v));
+    const float c = comp3(v, F.ma);
+    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
+    const float ss = (float)F.ss, ts = (float)F.ts, a = comp3(v, F.sa), b = comp3(v, F.ta);
+    g0 = make_float3(0.f, 0.f, 0.f); g1 = g0;
+    set3(g0, F.sa, dw.x * ss * h); set3(g0, F.ta, dw.z * ts * h); set3(g0, F.ma, -k * (dw.x * ss * a + dw.z * ts * b));
+    set3(g1, F.sa, dw.y * ss * h); set3(g1, F.ta, dw.w * ts * h); set3(g1, F.ma, -k * (dw.y * ss * a + dw.w * ts * b));
+    const bool ok = isfinite(g0.x) && isfinite(g0.y) && isfinite(g0.z) && isfinite(g1.x) && isfinite(g1.y) && isfinite(g1.z);
+    if (!ok) { g0 = make_float3(0.f, 0.f, 0.f); g1 = g0; }
+}
+
 // texture_kernel.cu:477-585
-template <int FILTER, bool BIAS_ONLY>
-__device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, int& level0, int& level1, float& flevel, float4* dw)
+template <int FILTER, bool BIAS_ONLY, bool CUBE = false>
+__device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, int& level0, int& level1, float& flevel, float4* dw,
+                                              float3 uv3 = make_float3(0.f, 0.f, 0.f), float3* dfdv = nullptr)
 {
 #pragma clang fp contract(off)
     level0 = 0; level1 = 0; flevel = 0.f;
     if (FILTER == TEX_NEAREST || FILTER == TEX_LINEAR) return;
     if (!BIAS_ONLY) {
-        const float4 d = ((const float4*)p.uvDA)[pidx];
+        float4 d;
+        float3 dvdX = make_float3(0.f, 0.f, 0.f), dvdY = dvdX;
+        if (CUBE) {
+            const float2* q = (const float2*)p.uvDA + pidx * 3;                 // (d/dX, d/dY) of x, y, z
+            const float2 d0 = q[0], d1 = q[1], d2 = q[2];
+            dvdX = make_float3(d0.x, d1.x, d2.x); dvdY = make_float3(d0.y, d1.y, d2.y);
+            d = cube_grad_st(uv3, dvdX, dvdY);
+        } else {
+            d = ((const float4*)p.uvDA)[pidx];
+        }
         const float uscl = (float)p.texW, vscl = (float)p.texH;
         const float dsdx = d.x * uscl, dsdy = d.y * uscl, dtdx = d.z * vscl, dtdy = d.w * vscl;
         const float A = dsdx * dsdx + dtdx * dtdx;
@@ -119,7 +304,13 @@ __device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, i
             const float l2aw = k * l2a;
             const float4 g = make_float4(uscl * (dsdx * (l2aw + AB) + dsdy * Cw), uscl * (dsdy * (l2aw - AB) + dsdx * Cw),
                                          vscl * (dtdx * (l2aw + AB) + dtdy * Cw), vscl * (dtdy * (l2aw - AB) + dtdx * Cw));
-            *dw = finite4(g) ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = finite4(g);
+            if (CUBE) {
+                const float3 fv = cube_grad2_dot(uv3, dvdX, dvdY, g);
+                ok = ok && isfinite(fv.x) && isfinite(fv.y) && isfinite(fv.z);
+                *dfdv = ok ? fv : make_float3(0.f, 0.f, 0.f);
+            }
+            *dw = ok ? g : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         flevel = .5f * log2f(lenMajorSqr);                                    // inf/NaN are fixed by the clamp
     }
@@ -130,6 +321,48 @@ __device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, i
         level1 = min(level0 + 1, p.levelMax);
         flevel -= (float)level0;
     }
+}
+
+// The four texels of channel c; at a cube corner the missing texel takes the average of the other
+// three (texture_kernel.cu:590-614).
+__device__ __forceinline__ void fetch_quad(const float* base, const Quad& q, int C, int c, float a[4])
+{
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] = q.tc[k] >= 0 ? base[q.tc[k] * C + c] : 0.f; sum += a[k]; }
+    if (q.corner) {
+        const float avg = sum * 0.33333333f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (q.tc[k] < 0) a[k] = avg;
+    }
+}
+
+// Scatter weights of the four taps; at a cube corner the missing texel's weight is shared by the other
+// three (texture_kernel.cu:616-639).
+__device__ __forceinline__ void corner_weights(const Quad& q, float w[4])
+{
+    if (!q.corner) return;
+    float cb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (q.tc[k] < 0) cb = w[k];
+    cb *= 0.33333333f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] += cb;
+}
+
+// Nearest texel of a cube map (:331-338): no wrap, the face is folded into the slice index.
+__device__ __forceinline__ long long tex_index_nearest_cube(const TexParams& p, float3 v, int tz, int& x, int& y)
+{
+#pragma clang fp contract(off)
+    float s, t;
+    const int f = cube_index(v, s, t);
+    if (f < 0) return -1;
+    const int w = p.texW;
+    int iu = __float2int_rd(s * (float)w), iv = __float2int_rd(t * (float)w);
+    iu = min(max(iu, 0), w - 1);
+    iv = min(max(iv, 0), w - 1);
+    x = iu; y = iv + w * f;
+    return (long long)iu + (long long)w * (y + 6ll * tz * w);
 }
 
 __device__ __forceinline__ float lerp1(float a, float b, float c) { return a + c * (b - a); }
@@ -189,7 +422,7 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
         if (C_CT > 0) {
             float t[CMAX];
             load_texel<C_CT>(t, p.tex[0], tc, C);
-            if (C_CT == 4) *(float4*)pOut = make_float4(t[0], t[1], t[2], t[3 % CMAX]);
+            if (C_CT == 4) *(float4*)pOut = make_float4(t[0], t[1 % CMAX], t[2 % CMAX], t[3 % CMAX]);
             else if (C_CT == 2) *(float2*)pOut = make_float2(t[0], t[1 % CMAX]);
             else for (int c = 0; c < C_CT; c++) pOut[c] = t[c];
         } else {
@@ -237,6 +470,44 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
     }
 }
 
+// Cube-map forward: same pixel mapping, direction vectors instead of (u,v), footprints that may cross
+// a face edge (three faces at a corner).  Generic channel loop.
+template <int FILTER, bool BIAS_ONLY>
+__global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
+{
+    int px, py, pz; bool inside;
+    if (!tex_pixel(p, px, py, pz, inside) || !inside) return;
+    const int C = p.channels;
+    const int tz = (p.texDepth == 1) ? 0 : pz;
+    const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
+    const float* puv = p.uv + pidx * 3;
+    const float3 uv3 = make_float3(puv[0], puv[1], puv[2]);
+    float* pOut = p.out + pidx * C;
+
+    if (FILTER == TEX_NEAREST) {
+        int x, y;
+        const long long tc = tex_index_nearest_cube(p, uv3, tz, x, y);
+        for (int c = 0; c < C; c++) pOut[c] = tc >= 0 ? p.tex[0][tc * C + c] : 0.f;
+        return;
+    }
+    int level0, level1; float flevel;
+    tex_mip_level<FILTER, BIAS_ONLY, true>(p, pidx, level0, level1, flevel, nullptr, uv3, nullptr);
+    const Quad q0 = tex_index_linear_cube(p, uv3, tz, level0);
+    const bool second = (FILTER == TEX_LML) && flevel > 0.f;
+    Quad q1 = q0;
+    if (second) q1 = tex_index_linear_cube(p, uv3, tz, level1);
+    for (int c = 0; c < C; c++) {
+        float a[4];
+        fetch_quad(p.tex[level0], q0, C, c, a);
+        float r = bilerp1(a[0], a[1], a[2], a[3], q0.fu, q0.fv);
+        if (second) {
+            fetch_quad(p.tex[level1], q1, C, c, a);
+            r = lerp1(r, bilerp1(a[0], a[1], a[2], a[3], q1.fu, q1.fv), flevel);
+        }
+        pOut[c] = r;
+    }
+}
+
 // ---- backward (texture_kernel.cu:905-1140) -------------------------------------------------
 
 // Texel-gradient accumulator of one workgroup: an LDS open-addressing table of 8x2-texel patches
@@ -276,7 +547,7 @@ struct PatchTable {
     }
 };
 
-template <int FILTER, bool BIAS_ONLY>
+template <int FILTER, bool BIAS_ONLY, bool CUBE>
 __global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
@@ -303,9 +574,15 @@ __global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
         active = !(__int_as_float((int)dmax) == 0.f);
         if (!active) {
             m = 0.f;
-            if (FILTER != TEX_NEAREST) ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
+            if (FILTER != TEX_NEAREST) {
+                if (CUBE) { float* g = p.gradUV + pidx * 3; g[0] = 0.f; g[1] = 0.f; g[2] = 0.f; }
+                else ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
+            }
             if (FILTER == TEX_LML) {
-                if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.gradUVDA) {
+                    if (CUBE) { float2* g = (float2*)p.gradUVDA + pidx * 3; g[0] = g[1] = g[2] = make_float2(0.f, 0.f); }
+                    else ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 if (p.gradBias) p.gradBias[pidx] = 0.f;
             }
         }
@@ -328,120 +605,145 @@ __global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
         // The four taps of a bilinear footprint share patches most of the time: look each patch up once.
         sl[0] = sl[1] = sl[2] = sl[3] = -1;
         if (direct || (p.dbg & 1024)) return;
-        if (q.tc[0] >= 0) sl[0] = tab.find(level, q.x0, q.y0);
-        if (q.tc[1] >= 0) sl[1] = (q.tc[0] >= 0 && sl[0] >= 0 && (q.x1 >> 3) == (q.x0 >> 3)) ? (sl[0] & ~7) + (q.x1 & 7) : tab.find(level, q.x1, q.y0);
-        if (q.tc[2] >= 0) sl[2] = (q.tc[0] >= 0 && sl[0] >= 0 && (q.y1 >> 1) == (q.y0 >> 1)) ? (sl[0] & ~15) + (q.y1 & 1) * 8 + (q.x0 & 7) : tab.find(level, q.x0, q.y1);
-        if (q.tc[3] >= 0) {
-            if (q.tc[2] >= 0 && sl[2] >= 0 && (q.x1 >> 3) == (q.x0 >> 3)) sl[3] = (sl[2] & ~7) + (q.x1 & 7);
-            else if (q.tc[1] >= 0 && sl[1] >= 0 && (q.y1 >> 1) == (q.y0 >> 1)) sl[3] = (sl[1] & ~15) + (q.y1 & 1) * 8 + (q.x1 & 7);
-            else sl[3] = tab.find(level, q.x1, q.y1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (q.tc[k] < 0) continue;
+            bool reused = false;
+#pragma unroll
+            for (int j = 0; j < k; j++) {
+                if (!reused && q.tc[j] >= 0 && sl[j] >= 0 && (q.tx[k] >> 3) == (q.tx[j] >> 3) && (q.ty[k] >> 1) == (q.ty[j] >> 1)) {
+                    sl[k] = (sl[j] & ~15) + (q.ty[k] & 1) * 8 + (q.tx[k] & 7);
+                    reused = true;
+                }
+            }
+            if (!reused) sl[k] = tab.find(level, q.tx[k], q.ty[k]);
         }
     };
 
     // Pixels that land on exactly the same texels (constant uv: backgrounds, flat regions under
     // magnification) would serialise on one LDS address; consecutive lanes with identical footprints
     // are summed in registers first (RunScan) and only the last lane of a run scatters.
+    auto same_quad = [&](const Quad& q) {
+        const int xa = q.tx[0] | (q.tx[1] << 16), xb = q.tx[2] | (q.tx[3] << 16);
+        int same = (int)(RunScan::prev_lane(xa, -1) == xa) & (int)(RunScan::prev_lane(xb, -1) == xb);
+#pragma unroll
+        for (int k = 0; k < 4; k++) same &= (int)(RunScan::prev_lane(q.ty[k], -1) == q.ty[k]);
+        const int valid = (q.tc[0] >= 0 ? 1 : 0) | (q.tc[1] >= 0 ? 2 : 0) | (q.tc[2] >= 0 ? 4 : 0) | (q.tc[3] >= 0 ? 8 : 0);
+        same &= (int)(RunScan::prev_lane(valid, -1) == valid);
+        return same;
+    };
     auto run_of = [&](const Quad& a, int la, const Quad& b, int lb, bool second) {
         const int f = la | (lb << 8) | ((second ? 1 : 0) << 16);
         int same = RunScan::prev_lane(f, -1) == f;
-        same &= (int)(RunScan::prev_lane(a.x0, 0) == a.x0) & (int)(RunScan::prev_lane(a.x1, 0) == a.x1);
-        same &= (int)(RunScan::prev_lane(a.y0, 0) == a.y0) & (int)(RunScan::prev_lane(a.y1, 0) == a.y1);
-        same &= (int)(RunScan::prev_lane(b.x0, 0) == b.x0) & (int)(RunScan::prev_lane(b.x1, 0) == b.x1);
-        same &= (int)(RunScan::prev_lane(b.y0, 0) == b.y0) & (int)(RunScan::prev_lane(b.y1, 0) == b.y1);
+        same &= same_quad(a);
+        same &= same_quad(b);
         return RunScan(RunScan::FromHead{}, !same, true);
     };
 
     // ---- phase B --------------------------------------------------------------------------------
     if (active) {
-        const float2 uv = ((const float2*)p.uv)[pidx];
+        float3 uv3 = make_float3(0.f, 0.f, 0.f);
+        if (CUBE) { const float* q = p.uv + pidx * 3; uv3 = make_float3(q[0], q[1], q[2]); }
+        else { const float2 t = ((const float2*)p.uv)[pidx]; uv3 = make_float3(t.x, t.y, 0.f); }
+        auto footprint = [&](int level) { return CUBE ? tex_index_linear_cube(p, uv3, tz, level) : tex_index_linear(p, uv3.x, uv3.y, tz, level); };
+
         if (FILTER == TEX_NEAREST) {
-            const long long tc = tex_index_nearest(p, uv.x, uv.y, tz);
+            int x = 0, y = 0;
+            long long tc;
+            if (CUBE) tc = tex_index_nearest_cube(p, uv3, tz, x, y);
+            else {
+                tc = tex_index_nearest(p, uv3.x, uv3.y, tz);
+                if (tc >= 0) { const long long t = tc - (long long)tz * p.texW * p.texH; y = (int)(t / p.texW); x = (int)(t - (long long)y * p.texW); }
+            }
             if (tc >= 0) {
-                const long long t = tc - (long long)tz * p.texW * p.texH;
-                const int y = (int)(t / p.texW), x = (int)(t - (long long)y * p.texW);
                 const int sl = direct ? -1 : tab.find(0, x, y);
                 for (int c = 0; c < C; c++) scatter(sl, 0, tc, c, pDy[c]);
             }
         } else {
             float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+            float3 dfdv = make_float3(0.f, 0.f, 0.f);
             int level0, level1; float flevel;
-            tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, &dw);
+            tex_mip_level<FILTER, BIAS_ONLY, CUBE>(p, pidx, level0, level1, flevel, &dw, uv3, &dfdv);
 
-            const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
+            const Quad q0 = footprint(level0);
             const float* pIn0 = p.tex[level0];
             const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
             const float tw0[4] = {w000, w010, w001, w011};
             const float sclu0 = (float)level_dim(p.texW, level0), sclv0 = (float)level_dim(p.texH, level0);
             int sl0[4];
             slots_of(q0, level0, sl0);
-            float gu = 0.f, gv = 0.f;
+            float gu = 0.f, gv = 0.f, df = 0.f;
 
-            if (FILTER == TEX_LINEAR || FILTER == TEX_LMN) {
-                const RunScan rs = run_of(q0, level0, q0, level0, false);
-                for (int c = 0; c < C; c++) {
-                    const float d = pDy[c];
-                    float v0[4] = {tw0[0] * d, tw0[1] * d, tw0[2] * d, tw0[3] * d};
-                    float z = 0.f;
-                    if (rs.any_merge()) { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], z, z); }
-                    if (rs.tail) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) scatter(sl0[k], level0, q0.tc[k], c, v0[k]);
-                    }
-                    const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
-                    const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
-                    const float ad = (a11 + a00 - a10 - a01);
-                    gu += d * ((a10 - a00) + q0.fv * ad) * sclu0;
-                    gv += d * ((a01 - a00) + q0.fu * ad) * sclv0;
-                }
-                ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
-            } else {
-                // Trilinear.
-                float df = 0.f;
-                const Quad q1 = tex_index_linear(p, uv.x, uv.y, tz, level1);
-                const float* pIn1 = p.tex[level1];
+            constexpr bool kTri = (FILTER == TEX_LML);
+            const bool second = kTri && flevel > 0.f;
+            Quad q1 = q0;
+            const float* pIn1 = pIn0;
+            float tw1[4] = {0.f, 0.f, 0.f, 0.f}, sclu1 = 0.f, sclv1 = 0.f;
+            int sl1[4] = {-1, -1, -1, -1};
+            if (kTri) {
+                q1 = footprint(level1);
+                pIn1 = p.tex[level1];
                 const float w111 = q1.fu * q1.fv, w110 = q1.fu - w111, w101 = q1.fv - w111, w100 = 1.f - q1.fu - w101;
-                const float tw1[4] = {w100, w110, w101, w111};
-                const float sclu1 = (float)level_dim(p.texW, level1), sclv1 = (float)level_dim(p.texH, level1);
-                int sl1[4] = {-1, -1, -1, -1};
-                if (flevel > 0.f) slots_of(q1, level1, sl1);
-                const bool second = flevel > 0.f;
-                const RunScan rs = run_of(q0, level0, q1, level1, second);
-                for (int c = 0; c < C; c++) {
-                    const float d = pDy[c];
-                    const float d0 = (1.f - flevel) * d;
-                    const float d1s = second ? flevel * d : 0.f;
-                    float v0[4] = {tw0[0] * d0, tw0[1] * d0, tw0[2] * d0, tw0[3] * d0};
-                    float v1[4] = {tw1[0] * d1s, tw1[1] * d1s, tw1[2] * d1s, tw1[3] * d1s};
-                    float z = 0.f;
-                    if (rs.any_merge()) { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], v1[0], v1[1]); rs.scan3(v1[2], v1[3], z); }
-                    if (rs.tail) {
+                tw1[0] = w100; tw1[1] = w110; tw1[2] = w101; tw1[3] = w111;
+                sclu1 = (float)level_dim(p.texW, level1); sclv1 = (float)level_dim(p.texH, level1);
+                if (second) slots_of(q1, level1, sl1);
+            }
+            const RunScan rs = run_of(q0, level0, q1, level1, second);
+            for (int c = 0; c < C; c++) {
+                const float d = pDy[c];
+                const float d0 = kTri ? (1.f - flevel) * d : d;
+                const float d1 = second ? flevel * d : 0.f;
+                float v0[4] = {tw0[0] * d0, tw0[1] * d0, tw0[2] * d0, tw0[3] * d0};
+                float v1[4] = {tw1[0] * d1, tw1[1] * d1, tw1[2] * d1, tw1[3] * d1};
+                if (CUBE) { corner_weights(q0, v0); if (kTri) corner_weights(q1, v1); }
+                float z = 0.f;
+                if (rs.any_merge()) {
+                    if (kTri) { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], v1[0], v1[1]); rs.scan3(v1[2], v1[3], z); }
+                    else      { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], z, z); }
+                }
+                if (rs.tail) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) scatter(sl0[k], level0, q0.tc[k], c, v0[k]);
-                        if (second) {
+                    for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) scatter(sl0[k], level0, q0.tc[k], c, v0[k]);
+                    if (second) {
 #pragma unroll
-                            for (int k = 0; k < 4; k++) if (q1.tc[k] >= 0) scatter(sl1[k], level1, q1.tc[k], c, v1[k]);
-                        }
-                    }
-                    const float a00 = q0.tc[0] >= 0 ? pIn0[q0.tc[0] * C + c] : 0.f, a10 = q0.tc[1] >= 0 ? pIn0[q0.tc[1] * C + c] : 0.f;
-                    const float a01 = q0.tc[2] >= 0 ? pIn0[q0.tc[2] * C + c] : 0.f, a11 = q0.tc[3] >= 0 ? pIn0[q0.tc[3] * C + c] : 0.f;
-                    const float ad = (a11 + a00 - a10 - a01);
-                    gu += d0 * ((a10 - a00) + q0.fv * ad) * sclu0;
-                    gv += d0 * ((a01 - a00) + q0.fu * ad) * sclv0;
-                    if (flevel > 0.f) {
-                        const float d1 = flevel * d;
-                        const float b00 = q1.tc[0] >= 0 ? pIn1[q1.tc[0] * C + c] : 0.f, b10 = q1.tc[1] >= 0 ? pIn1[q1.tc[1] * C + c] : 0.f;
-                        const float b01 = q1.tc[2] >= 0 ? pIn1[q1.tc[2] * C + c] : 0.f, b11 = q1.tc[3] >= 0 ? pIn1[q1.tc[3] * C + c] : 0.f;
-                        const float bd = (b11 + b00 - b10 - b01);
-                        gu += d1 * ((b10 - b00) + q1.fv * bd) * sclu1;
-                        gv += d1 * ((b01 - b00) + q1.fu * bd) * sclv1;
-                        const float a = bilerp1(a00, a10, a01, a11, q0.fu, q0.fv);
-                        const float b = bilerp1(b00, b10, b01, b11, q1.fu, q1.fv);
-                        df += (b - a) * d;
+                        for (int k = 0; k < 4; k++) if (q1.tc[k] >= 0) scatter(sl1[k], level1, q1.tc[k], c, v1[k]);
                     }
                 }
+                float a[4];
+                fetch_quad(pIn0, q0, C, c, a);
+                const float ad = (a[3] + a[0] - a[1] - a[2]);
+                gu += d0 * ((a[1] - a[0]) + q0.fv * ad) * sclu0;
+                gv += d0 * ((a[2] - a[0]) + q0.fu * ad) * sclv0;
+                if (second) {
+                    const float dd1 = flevel * d;
+                    float b[4];
+                    fetch_quad(pIn1, q1, C, c, b);
+                    const float bd = (b[3] + b[0] - b[1] - b[2]);
+                    gu += dd1 * ((b[1] - b[0]) + q1.fv * bd) * sclu1;
+                    gv += dd1 * ((b[2] - b[0]) + q1.fu * bd) * sclv1;
+                    df += (bilerp1(b[0], b[1], b[2], b[3], q1.fu, q1.fv) - bilerp1(a[0], a[1], a[2], a[3], q0.fu, q0.fv)) * d;
+                }
+            }
+            if (CUBE) {
+                const float3 g3 = cube_grad(uv3, gu, gv);
+                float* g = p.gradUV + pidx * 3;
+                g[0] = kTri ? g3.x + dfdv.x * df : g3.x;
+                g[1] = kTri ? g3.y + dfdv.y * df : g3.y;
+                g[2] = kTri ? g3.z + dfdv.z * df : g3.z;
+            } else {
                 ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+            }
+            if (kTri) {
                 if (p.gradBias) p.gradBias[pidx] = df;
-                if (!BIAS_ONLY && p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(dw.x * df, dw.y * df, dw.z * df, dw.w * df);
+                if (!BIAS_ONLY && p.gradUVDA) {
+                    const float4 dwf = make_float4(dw.x * df, dw.y * df, dw.z * df, dw.w * df);
+                    if (CUBE) {
+                        float3 g0, g1;
+                        cube_grad4(uv3, dwf, g0, g1);
+                        float2* g = (float2*)p.gradUVDA + pidx * 3;
+                        g[0] = make_float2(g0.x, g1.x); g[1] = make_float2(g0.y, g1.y); g[2] = make_float2(g0.z, g1.z);
+                    } else ((float4*)p.gradUVDA)[pidx] = dwf;
+                }
             }
         }
     }
@@ -462,7 +764,7 @@ __global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
         const int level = (int)(key >> 58) - 1;
         const int x = (int)(key & 0x1FFFFFFFull) * 8 + (tx & 7);
         const int y = (int)((key >> 29) & 0x1FFFFFFFull) * 2 + (tx >> 3);
-        const int w = level_dim(p.texW, level), h = level_dim(p.texH, level);
+        const int w = level_dim(p.texW, level), h = level_dim(p.texH, level) * (CUBE ? 6 : 1);
         if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
         atomic_add_f32(p.gradTex[level] + (((long long)tz * h + y) * w + x) * C + c, fs.to_float(t));
     }
@@ -549,10 +851,16 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
 {
     NVDR_REQUIRE(filter >= 0 && filter < 4, "filter_mode unsupported");
     NVDR_REQUIRE(boundary >= 0 && boundary < 4, "boundary_mode unsupported");
-    NVDR_REQUIRE(boundary != TEX_B_CUBE, "%s: cube map textures are not implemented in this build (2D textures only)", who);
+    const bool cube = (boundary == TEX_B_CUBE);
     NVDR_REQUIRE(tex && uv, "%s: null pointer", who);
-    NVDR_REQUIRE(tex_n > 0 && tex_h > 0 && tex_w > 0 && C > 0, "tex must have shape[>0, >0, >0, >0]");
-    NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "uv must have shape [>0, >0, >0, 2]");
+    if (cube) {
+        NVDR_REQUIRE(tex_n > 0 && tex_h > 0 && tex_w > 0 && C > 0, "tex must have shape[>0, 6, >0, >0, >0] in cube map mode");
+        NVDR_REQUIRE(tex_h == tex_w, "texture shape must be square in cube map mode");
+        NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "uv must have shape [>0, >0, >0, 3] in cube map mode");
+    } else {
+        NVDR_REQUIRE(tex_n > 0 && tex_h > 0 && tex_w > 0 && C > 0, "tex must have shape[>0, >0, >0, >0]");
+        NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "uv must have shape [>0, >0, >0, 2]");
+    }
     NVDR_REQUIRE(tex_n == 1 || tex_n == N, "minibatch size mismatch between inputs tex, uv");
     NVDR_REQUIRE(tex_w <= (1 << 16) && tex_h <= (1 << 16), "texture size too large");
     const bool mips = (filter == TEX_LMN || filter == TEX_LML);
@@ -561,8 +869,12 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
         NVDR_REQUIRE(L >= 0 && L < kTexMaxLevels, "%s: bad mip level count %d", who, L);
         NVDR_REQUIRE(L == 0 || mip_ptrs_host, "mipmapping filter mode requires mip wrapper or mip stack input");
     }
-    NVDR_REQUIRE(!((uintptr_t)uv & 7), "uv input tensor not aligned to float2");
-    NVDR_REQUIRE(!((uintptr_t)uv_da & 15), "uv_da input tensor not aligned to float4");
+    if (!cube) {
+        NVDR_REQUIRE(!((uintptr_t)uv & 7), "uv input tensor not aligned to float2");
+        NVDR_REQUIRE(!((uintptr_t)uv_da & 15), "uv_da input tensor not aligned to float4");
+    } else {
+        NVDR_REQUIRE(!((uintptr_t)uv_da & 7), "uv_da input tensor not aligned to float2");
+    }
     p = TexParams{};
     p.tex[0] = tex;
     p.levelMax = mips ? L : 0;
@@ -598,12 +910,13 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
                                           int max_mip_level, float* mip, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    NVDR_REQUIRE(!cube, "texture_construct_mip: cube map textures are not implemented in this build (2D textures only)");
     NVDR_REQUIRE(max_mip_level >= -1, "invalid max_mip_level");
+    NVDR_REQUIRE(!cube || tex_h == tex_w, "texture shape must be square in cube map mode");
     NVDR_REQUIRE(tex && tex_n > 0 && tex_h > 0 && tex_w > 0 && C > 0, "tex must have shape[>0, >0, >0, >0]");
     NVDR_REQUIRE(tex_w <= (1 << 16) && tex_h <= (1 << 16), "texture size too large");
     int lw[kTexMaxLevels], lh[kTexMaxLevels]; int64_t off[kTexMaxLevels], total;
-    const int L = mip_info(tex_n, tex_h, tex_w, C, 0, max_mip_level, lw, lh, off, &total);
+    const int depth = cube ? tex_n * 6 : tex_n;                             // six faces per slice
+    const int L = mip_info(depth, tex_h, tex_w, C, 0, max_mip_level, lw, lh, off, &total);
     if (L < 0) {                                                             // texture.cpp:15-60 raiseMipSizeError
         set_error("texture_construct_mip: texture extents %d x %d cannot be halved down to 1 (odd size at a mip level); "
                   "use a power-of-two size, or limit max_mip_level", tex_w, tex_h);
@@ -614,8 +927,8 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
         MipParams mp;
         mp.in = (l == 1) ? tex : mip + off[l - 1];
         mp.out = mip + off[l];
-        mp.wi = lw[l - 1]; mp.hi = lh[l - 1]; mp.wo = lw[l]; mp.ho = lh[l]; mp.depth = tex_n; mp.C = C;
-        const long long total_out = (long long)mp.wo * mp.ho * tex_n * C;
+        mp.wi = lw[l - 1]; mp.hi = lh[l - 1]; mp.wo = lw[l]; mp.ho = lh[l]; mp.depth = depth; mp.C = C;
+        const long long total_out = (long long)mp.wo * mp.ho * depth * C;
         ProfileScope ps("tex_mip_build", stream);
         hipLaunchKernelGGL(k_mip_build, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, stream, mp);
     }
@@ -648,7 +961,17 @@ extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_h
     for (int i = 0; i <= p.levelMax; i++) { vec4 = vec4 && !((uintptr_t)p.tex[i] & 15); vec2 = vec2 && !((uintptr_t)p.tex[i] & 7); }
     const dim3 grid = tex_grid(p);
     const bool bo = (p.levelMax >= 0) && (filter_mode >= TEX_LMN) && !p.uvDA;
-    {
+    if (boundary_mode == TEX_B_CUBE) {
+        ProfileScope ps("tex_fwd_cube", stream);
+        switch (filter_mode) {
+        case TEX_NEAREST: hipLaunchKernelGGL((k_tex_fwd_cube<TEX_NEAREST, false>), grid, dim3(256), 0, stream, p); break;
+        case TEX_LINEAR:  hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LINEAR, false>), grid, dim3(256), 0, stream, p); break;
+        case TEX_LMN:     if (bo) hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LMN, true>), grid, dim3(256), 0, stream, p);
+                          else    hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LMN, false>), grid, dim3(256), 0, stream, p); break;
+        default:          if (bo) hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LML, true>), grid, dim3(256), 0, stream, p);
+                          else    hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LML, false>), grid, dim3(256), 0, stream, p); break;
+        }
+    } else {
         ProfileScope ps("tex_fwd", stream);
         switch (filter_mode) {
         case TEX_NEAREST: NVDR_TEX_FWD_C(TEX_NEAREST, false); break;
@@ -675,8 +998,13 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     if (rc) return rc;
     NVDR_REQUIRE(dy && g_tex, "texture_grad: null pointer");
     NVDR_REQUIRE(filter_mode == TEX_NEAREST || g_uv, "texture_grad: g_uv missing");
-    NVDR_REQUIRE(!((uintptr_t)g_uv & 7), "grad_uv output tensor not aligned to float2");
-    NVDR_REQUIRE(!((uintptr_t)g_uv_da & 15), "grad_uv_da output tensor not aligned to float4");
+    const bool cube = (boundary_mode == TEX_B_CUBE);
+    if (!cube) {
+        NVDR_REQUIRE(!((uintptr_t)g_uv & 7), "grad_uv output tensor not aligned to float2");
+        NVDR_REQUIRE(!((uintptr_t)g_uv_da & 15), "grad_uv_da output tensor not aligned to float4");
+    } else {
+        NVDR_REQUIRE(!((uintptr_t)g_uv_da & 7), "grad_uv_da output tensor not aligned to float2");
+    }
     p.dy = dy;
     p.gradTex[0] = g_tex;
     for (int i = 1; i <= p.levelMax; i++) {
@@ -698,21 +1026,24 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     const size_t lds = (size_t)groups * (8 + 128 * (size_t)C) + 16;
     {
         ProfileScope ps("tex_grad", stream);
+#define NVDR_TEX_GRAD(FILTER, BO)                                                                              \
+    do {                                                                                                       \
+        if (cube) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, true>), grid, dim3(256), lds, stream, p, groups);  \
+        else      hipLaunchKernelGGL((k_tex_grad<FILTER, BO, false>), grid, dim3(256), lds, stream, p, groups); \
+    } while (0)
         switch (filter_mode) {
-        case TEX_NEAREST: hipLaunchKernelGGL((k_tex_grad<TEX_NEAREST, false>), grid, dim3(256), lds, stream, p, groups); break;
-        case TEX_LINEAR:  hipLaunchKernelGGL((k_tex_grad<TEX_LINEAR, false>), grid, dim3(256), lds, stream, p, groups); break;
-        case TEX_LMN:     if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LMN, true>), grid, dim3(256), lds, stream, p, groups);
-                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LMN, false>), grid, dim3(256), lds, stream, p, groups); break;
-        default:          if (bo) hipLaunchKernelGGL((k_tex_grad<TEX_LML, true>), grid, dim3(256), lds, stream, p, groups);
-                          else    hipLaunchKernelGGL((k_tex_grad<TEX_LML, false>), grid, dim3(256), lds, stream, p, groups); break;
+        case TEX_NEAREST: NVDR_TEX_GRAD(TEX_NEAREST, false); break;
+        case TEX_LINEAR:  NVDR_TEX_GRAD(TEX_LINEAR, false); break;
+        case TEX_LMN:     if (bo) NVDR_TEX_GRAD(TEX_LMN, true); else NVDR_TEX_GRAD(TEX_LMN, false); break;
+        default:          if (bo) NVDR_TEX_GRAD(TEX_LML, true); else NVDR_TEX_GRAD(TEX_LML, false); break;
         }
     }
     NVDR_LAUNCH_CHECK();
     if (pull_mip_grads && p.levelMax > 0) {                                  // torch_texture.cpp:679-687
         MipGradParams mg;
         for (int i = 0; i <= p.levelMax; i++) mg.gradTex[i] = p.gradTex[i];
-        mg.texW = tex_w; mg.texH = tex_h; mg.depth = tex_n; mg.C = C; mg.levelMax = p.levelMax;
-        const long long total = (long long)tex_w * tex_h * tex_n * C;
+        mg.texW = tex_w; mg.texH = tex_h; mg.depth = cube ? tex_n * 6 : tex_n; mg.C = C; mg.levelMax = p.levelMax;
+        const long long total = (long long)tex_w * tex_h * mg.depth * C;
         ProfileScope ps("tex_mip_grad", stream);
         hipLaunchKernelGGL(k_mip_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mg);
         NVDR_LAUNCH_CHECK();

@@ -383,7 +383,13 @@ def _check_tex_shape(fn, tex, cube_mode):
         _require(tex.dim() == 5 and tex.size(0) > 0 and tex.size(1) == 6 and tex.size(2) > 0 and tex.size(3) > 0 and tex.size(4) > 0,
                  fn, "tex must have shape[>0, 6, >0, >0, >0] in cube map mode")
         _require(tex.size(2) == tex.size(3), fn, "texture shape must be square in cube map mode")
-        _fail(fn, "cube map textures are not implemented in this build (2D textures only)")
+
+
+def _tex_dims(tex, cube_mode):
+    """(depth, height, width, channels) of a 2D texture [n,h,w,c] or a cube map [n,6,s,s,c]."""
+    if cube_mode:
+        return tex.size(0), tex.size(2), tex.size(3), tex.size(4)
+    return tex.size(0), tex.size(1), tex.size(2), tex.size(3)
 
 
 def texture_construct_mip(tex, max_mip_level, cube_mode):
@@ -397,7 +403,8 @@ def texture_construct_mip(tex, max_mip_level, cube_mode):
     L, lw, lh, off, total = _mip_info(tex.shape, cube_mode, max_mip_level, fn)
     with torch.cuda.device(dev):
         mip = torch.empty((total,), dtype=torch.float32, device=dev)
-        rc = _capi.load().nvdr_texture_construct_mip(tex.data_ptr(), tex.size(0), tex.size(1), tex.size(2), tex.size(3),
+        tn, th, tw, tc = _tex_dims(tex, cube_mode)
+        rc = _capi.load().nvdr_texture_construct_mip(tex.data_ptr(), tn, th, tw, tc,
                                                      int(cube_mode), int(max_mip_level), mip.data_ptr(), _stream(dev))
     _capi.check(rc, fn)
     w = TextureMipWrapper()
@@ -448,26 +455,40 @@ def _texture_common(fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, 
 
     cube_mode = boundary_mode == _BOUNDARY_CUBE
     _check_tex_shape(fn, tex, cube_mode)
-    _require(uv.dim() == 4 and uv.size(0) > 0 and uv.size(1) > 0 and uv.size(2) > 0 and uv.size(3) == 2, fn,
-             "uv must have shape [>0, >0, >0, 2]")
-    _require(tex.size(0) == 1 or tex.size(0) == uv.size(0), fn, "minibatch size mismatch between inputs tex, uv")
-    _require(tex.size(2) <= (1 << 16) and tex.size(1) <= (1 << 16), fn, "texture size too large")
+    if not cube_mode:
+        _require(uv.dim() == 4 and uv.size(0) > 0 and uv.size(1) > 0 and uv.size(2) > 0 and uv.size(3) == 2, fn,
+                 "uv must have shape [>0, >0, >0, 2]")
+    else:
+        _require(uv.dim() == 4 and uv.size(0) > 0 and uv.size(1) > 0 and uv.size(2) > 0 and uv.size(3) == 3, fn,
+                 "uv must have shape [>0, >0, >0, 3] in cube map mode")
+    tn, th, tw, tc = _tex_dims(tex, cube_mode)
+    _require(tn == 1 or tn == uv.size(0), fn, "minibatch size mismatch between inputs tex, uv")
+    _require(tw <= (1 << 16) and th <= (1 << 16), fn, "texture size too large")
     n, H, W = uv.size(0), uv.size(1), uv.size(2)
     if enable_mip:
         if has_uv_da:
-            _require(uv_da.dim() == 4 and tuple(uv_da.shape) == (n, H, W, 4), fn,
-                     "uv_da must have shape [minibatch_size, height, width, 4]")
+            if not cube_mode:
+                _require(uv_da.dim() == 4 and tuple(uv_da.shape) == (n, H, W, 4), fn,
+                         "uv_da must have shape [minibatch_size, height, width, 4]")
+            else:
+                _require(uv_da.dim() == 4 and tuple(uv_da.shape) == (n, H, W, 6), fn,
+                         "uv_da must have shape [minibatch_size, height, width, 6] in cube map mode")
         if has_bias:
             _require(mip_level_bias.dim() == 3 and tuple(mip_level_bias.shape) == (n, H, W), fn,
                      "mip_level_bias must have shape [minibatch_size, height, width]")
 
+    faces = 6 if cube_mode else 1
     levels, g_levels, g_flat = [], [], None
     if enable_mip:
         if has_stack:
             for i, t in enumerate(mip_stack, start=1):
-                sw, sh = max(tex.size(2) >> i, 1), max(tex.size(1) >> i, 1)
-                _require(t.dim() == 4 and t.size(0) == tex.size(0) and t.size(1) == sh and t.size(2) == sw and t.size(3) == tex.size(3),
-                         fn, "mip level size mismatch in custom mip stack")
+                sw, sh = max(tw >> i, 1), max(th >> i, 1)
+                if not cube_mode:
+                    _require(t.dim() == 4 and t.size(0) == tn and t.size(1) == sh and t.size(2) == sw and t.size(3) == tc,
+                             fn, "mip level size mismatch in custom mip stack")
+                else:
+                    _require(t.dim() == 5 and t.size(0) == tn and t.size(1) == 6 and t.size(2) == sh and t.size(3) == sw and t.size(4) == tc,
+                             fn, "mip level size mismatch in mip stack")
                 if sw == 1 and sh == 1:
                     _require(i == len(mip_stack), fn, "mip level size mismatch in mip stack")
                 levels.append(t)
@@ -479,7 +500,7 @@ def _texture_common(fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, 
             _require(list(tex.shape) == list(mip_wrapper.texture_size) and cube_mode == mip_wrapper.cube_mode, fn,
                      "mip does not match texture size")
             _require(mip_w.dim() == 1 and mip_w.size(0) == total, fn, "wrapped mip tensor size mismatch")
-            cnt = [tex.size(0) * lh[i] * lw[i] * tex.size(3) for i in range(L + 1)]
+            cnt = [tn * faces * lh[i] * lw[i] * tc for i in range(L + 1)]
             levels = [mip_w[off[i]:off[i] + cnt[i]] for i in range(1, L + 1)]
             if grad_mips:
                 g_flat = torch.zeros_like(mip_w)
@@ -492,14 +513,15 @@ def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filt
     fn = "texture_fwd_mip"
     dev, enable_mip, has_uv_da, has_bias, levels, _, _ = _texture_common(
         fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, list(mip_stack), filter_mode, boundary_mode, False)
-    n, H, W, C = uv.size(0), uv.size(1), uv.size(2), tex.size(3)
+    tn, th, tw, C = _tex_dims(tex, boundary_mode == _BOUNDARY_CUBE)
+    n, H, W = uv.size(0), uv.size(1), uv.size(2)
     ptrs, L = _capi.ptr_array(levels)
     with torch.cuda.device(dev):
         out = torch.empty((n, H, W, C), dtype=torch.float32, device=dev)
         rc = _capi.load().nvdr_texture_fwd(tex.data_ptr(), ptrs, L, uv.data_ptr(),
                                            uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
                                            mip_level_bias.data_ptr() if (enable_mip and has_bias) else None,
-                                           tex.size(0), tex.size(1), tex.size(2), C, n, H, W,
+                                           tn, th, tw, C, n, H, W,
                                            int(filter_mode), int(boundary_mode), out.data_ptr(), _stream(dev))
     _capi.check(rc, fn)
     return out
@@ -518,7 +540,8 @@ def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wr
         fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, True)
     _check_device(fn, dy=dy)
     _check_f32(fn, dy=dy)
-    n, H, W, C = uv.size(0), uv.size(1), uv.size(2), tex.size(3)
+    tn, th, tw, C = _tex_dims(tex, boundary_mode == _BOUNDARY_CUBE)
+    n, H, W = uv.size(0), uv.size(1), uv.size(2)
     _require(dy.dim() == 4 and tuple(dy.shape) == (n, H, W, C), fn, "dy must have shape [minibatch_size, height, width, channels]")
     dy_ = dy.contiguous()
     has_stack = len(mip_stack) > 0
@@ -537,7 +560,7 @@ def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wr
         rc = _capi.load().nvdr_texture_grad(tex.data_ptr(), ptrs, L, uv.data_ptr(),
                                             uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
                                             mip_level_bias.data_ptr() if (enable_mip and has_bias) else None,
-                                            dy_.data_ptr(), tex.size(0), tex.size(1), tex.size(2), C, n, H, W,
+                                            dy_.data_ptr(), tn, th, tw, C, n, H, W,
                                             int(filter_mode), int(boundary_mode), int(enable_mip and not has_stack),
                                             g_tex.data_ptr(), gptrs, _capi.ptr(g_uv), _capi.ptr(g_uv_da), _capi.ptr(g_bias),
                                             _stream(dev))

@@ -266,8 +266,9 @@ class _texture_func(torch.autograd.Function):
 def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
     """Texture sampling (reference ops.py:345-439).
 
-    tex: [N or 1, Ht, Wt, C] float32 (cube maps [N or 1, 6, S, S, C] with boundary_mode='cube' are not
-    implemented in this build); uv: [N,H,W,2]; uv_da: optional [N,H,W,4] image-space derivatives of uv;
+    tex: [N or 1, Ht, Wt, C] float32, or a cube map [N or 1, 6, S, S, C] with boundary_mode='cube';
+    uv: [N,H,W,2] (cube: direction vectors [N,H,W,3]); uv_da: optional image-space derivatives of uv,
+    [N,H,W,4] (cube: [N,H,W,6]);
     mip_level_bias: optional [N,H,W]; mip: a ``texture_construct_mip()`` result or a list of tensors
     (custom mip stack, levels 1..L, which then receive their own gradients); filter_mode: 'auto',
     'nearest', 'linear', 'linear-mipmap-nearest', 'linear-mipmap-linear' ('auto' = trilinear when

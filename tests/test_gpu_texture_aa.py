@@ -109,8 +109,8 @@ def test_mip_construction_and_reuse(dr, oracle):
         dr.texture_construct_mip(_t(rng.uniform(size=(1, 12, 8, 1)).astype(np.float32)))     # 12 -> 6 -> 3: odd
     with pytest.raises(RuntimeError, match="mip does not match texture size"):
         dr.texture(_t(rng.uniform(size=(1, 16, 16, 2)).astype(np.float32)), _t(uv), _t(da), mip=w)
-    with pytest.raises(RuntimeError, match="cube"):
-        dr.texture(torch.zeros(1, 6, 4, 4, 3, device="cuda"), torch.zeros(1, 2, 2, 3, device="cuda"), boundary_mode="cube")
+    with pytest.raises(RuntimeError, match="square in cube map mode"):
+        dr.texture(torch.zeros(1, 6, 4, 8, 3, device="cuda"), torch.zeros(1, 2, 2, 3, device="cuda"), boundary_mode="cube")
 
 
 def test_custom_mip_stack_gradients(dr, oracle):
@@ -129,6 +129,70 @@ def test_custom_mip_stack_gradients(dr, oracle):
     _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), 2e-3)
     for k in range(3):
         _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]), 2e-3)
+
+
+# ------------------------------------------------------------------------------ cube maps
+
+def _cube_dirs(rng, N, H, W):
+    v = rng.normal(size=(N, H, W, 3)).astype(np.float32)
+    v[0, 0] = np.array([1, 0.98, 0.1]) + rng.normal(size=(W, 3)) * 0.04       # hugging an edge
+    v[0, 1] = np.array([1, -1, 1]) + rng.normal(size=(W, 3)) * 0.03           # hugging a corner
+    v[0, 2] = np.array([-1, -1, -1]) + rng.normal(size=(W, 3)) * 0.03
+    v[0, 3, 0] = 0.0                                                          # invalid direction
+    return v.astype(np.float32)
+
+
+@pytest.mark.parametrize("fm", FILTERS)
+@pytest.mark.parametrize("C,tex_n", [(3, 1), (4, 2), (1, 1)])
+def test_cube_forward_backward(dr, oracle, fm, C, tex_n):
+    rng = np.random.default_rng(200 + C)
+    N, H, W = 2, 23, 19
+    tex = rng.uniform(size=(tex_n, 6, 16, 16, C)).astype(np.float32)
+    v = _cube_dirs(rng, N, H, W)
+    mip = "mipmap" in fm
+    da = (rng.normal(size=(N, H, W, 6)) * 0.2).astype(np.float32) if mip else None
+    bias = rng.uniform(-0.5, 0.5, size=(N, H, W)).astype(np.float32) if mip else None
+    dy = rng.normal(size=(N, H, W, C)).astype(np.float32)
+    dy[1, :2] = 0.0
+    kw = dict(filter_mode=fm, boundary_mode="cube")
+    t_tex = _t(tex).requires_grad_(True)
+    t_v = _t(v).requires_grad_(True)
+    t_da = _t(da).requires_grad_(True) if mip else None
+    t_bias = _t(bias).requires_grad_(True) if mip else None
+    out = dr.texture(t_tex, t_v, t_da, t_bias, **kw)
+    out.backward(_t(dy))
+    oo = oracle.texture(tex, v, da, bias, **kw)
+    g = oracle.texture_grad(tex, v, dy, da, bias, **kw)
+    frac = 3e-3 if mip else 0.0
+    _close(out.detach().cpu().numpy(), oo, ATOL, frac)
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), frac)
+    if fm != "nearest":
+        _close(t_v.grad.cpu().numpy(), g["uv"], _tol(g["uv"]) * 4, frac)
+    if fm == "linear-mipmap-linear":
+        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]) * 4, frac)
+        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]) * 4, frac)
+
+
+def test_cube_mips(dr, oracle):
+    rng = np.random.default_rng(210)
+    tex = rng.uniform(size=(2, 6, 8, 8, 3)).astype(np.float32)
+    w = dr.texture_construct_mip(_t(tex), cube_mode=True)
+    flat = np.concatenate([l.reshape(-1) for l in oracle.texture_build_mip(tex)])
+    assert np.abs(w.mip.cpu().numpy() - flat).max() <= 1e-6
+    v = _cube_dirs(rng, 2, 9, 9)
+    da = (rng.normal(size=(2, 9, 9, 6)) * 0.3).astype(np.float32)
+    a = dr.texture(_t(tex), _t(v), _t(da), mip=w, boundary_mode="cube")
+    b = dr.texture(_t(tex), _t(v), _t(da), boundary_mode="cube")
+    assert torch.equal(a, b)
+    # custom stack with its own gradients
+    levels = [rng.uniform(size=(2, 6, 8 >> k, 8 >> k, 3)).astype(np.float32) for k in (1, 2)]
+    t_lv = [_t(l).requires_grad_(True) for l in levels]
+    dy = rng.normal(size=(2, 9, 9, 3)).astype(np.float32)
+    o = dr.texture(_t(tex), _t(v), _t(da), mip=t_lv, boundary_mode="cube")
+    o.backward(_t(dy))
+    g = oracle.texture_grad(tex, v, dy, da, mip=levels, boundary_mode="cube")
+    for k in range(2):
+        _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]), 3e-3)
 
 
 # ------------------------------------------------------------------------------ antialias
