@@ -40,9 +40,12 @@ constexpr uint32_t kEmptyBox  = 0x000000FFu;             // txlo=255 > txhi=0
 constexpr int      kSubPerTri = 7;                       // clipper output: <= 9 verts -> <= 7 tris
 
 constexpr int kBinTiles   = 8;                           // bin = 8x8 tiles = 64x64 px
-constexpr int kFineWaves  = 8;
+constexpr int kMaxBins    = 1024;                        // (2048 / 64)^2 bins per viewport tile
+constexpr int kFineWaves  = 8;                           // one wave per row of eight 8x8 tiles
 constexpr int kFineThreads = kFineWaves * 64;
-constexpr int kListCap    = 448;                         // LDS triangle list capacity
+constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in the pair ring)
+constexpr int kWavesPerRow = kFineWaves / kBinTiles;        // waves sharing one row of eight 8x8 tiles
+constexpr int kTilesPerWave = kBinTiles / kWavesPerRow;
 
 struct Viewport {
     int   vpw, vph;            // viewport size in pixels (unpadded)
@@ -56,6 +59,7 @@ struct SetupParams {
     Viewport vp;
     uint4* rec; uint32_t* bbox; int* poolCount;
     int* binCount; int binsX, binsY;       // per (image, 64x64 bin) triangle counts, filled here
+    int* binHi; int* binLoInv;             // per bin: (max direct slot) + 1 and INT_MAX - (min direct slot); 0 = none
 };
 
 // ---------------------------------------------------------------------------------
@@ -204,7 +208,14 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     uint32_t box = (uint32_t)(x0 >> 3) | ((uint32_t)(y0 >> 3) << 8) | ((uint32_t)(x1 >> 3) << 16) | ((uint32_t)(y1 >> 3) << 24);
     for (int by_ = y0 >> 6; by_ <= (y1 >> 6); by_++)
         for (int bx_ = x0 >> 6; bx_ <= (x1 >> 6); bx_++)
-            atomicAdd(&s_hist[by_ * p.binsX + bx_], 1);
+        {
+            const int b = by_ * p.binsX + bx_;
+            atomicAdd(&s_hist[b], 1);
+            if (slot < p.poolBase) {                                  // index range of the bin's direct slots
+                atomicMax(&s_hist[kMaxBins + b], slot + 1);
+                atomicMax(&s_hist[2 * kMaxBins + b], 0x7FFFFFFF - slot);
+            }
+        }
 
     uint32_t A[3], B[3], C[3];
 #pragma unroll
@@ -341,13 +352,12 @@ __device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, in
     }
 }
 
-constexpr int kMaxBins = 1024;          // (2048 / 64)^2 bins per viewport tile
 
 __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
 {
-    __shared__ int s_hist[kMaxBins];
+    __shared__ int s_hist[3 * kMaxBins];              // per bin: count, max slot + 1, INT_MAX - min slot
     const int nb = p.binsX * p.binsY;
-    for (int b = threadIdx.x; b < nb; b += 256) s_hist[b] = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) { s_hist[b] = 0; s_hist[kMaxBins + b] = 0; s_hist[2 * kMaxBins + b] = 0; }
     __syncthreads();
     const int n = blockIdx.y;
     setup_one(p, n, blockIdx.x * 256 + threadIdx.x, s_hist);
@@ -355,7 +365,11 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
     // One global atomic per non-empty bin per block (instead of one per triangle).
     for (int b = threadIdx.x; b < nb; b += 256) {
         int c = s_hist[b];
-        if (c) atomicAdd(&p.binCount[(size_t)n * nb + b], c);
+        if (c) {
+            const size_t o = (size_t)n * nb + b;
+            atomicAdd(&p.binCount[o], c);
+            if (s_hist[kMaxBins + b]) { atomicMax(&p.binHi[o], s_hist[kMaxBins + b]); atomicMax(&p.binLoInv[o], s_hist[2 * kMaxBins + b]); }
+        }
     }
 }
 
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount
 
 struct FineParams {
     const uint4* rec; const uint32_t* bbox; const int* poolCount; const int* ranges;
-    const int* binCount; const int* order;
+    const int* binCount; const int* order; const int* binHi; const int* binLoInv;
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
@@ -408,14 +422,17 @@ struct FineParams {
     unsigned long long* dbgbuf;    // development: per-workgroup phase timestamps
 };
 
-constexpr int kQueueSize = 128;    // per-wave (triangle, tile) pair ring
+
+constexpr int kQueueSize = 128;
 
 struct FineShared {
     uint32_t slot[kListCap];                               // bin triangle list: record slot of each entry
     uint32_t box[kListCap];                                // packed tile AABBs of the list entries
     unsigned long long key[kBinTiles][kBinTiles][64];      // per-pixel visibility keys of the bin [tileY][tileX][pixel]
-    uint32_t queue[kFineWaves][kQueueSize];                // pair ring: entry | tileX << 16 | tileY << 20
+    uint32_t pfx[kListCap + 64];                           // exclusive prefix of the entries' (triangle, tile) pair counts
+    uint16_t queue[kFineWaves][kQueueSize];                // per-wave ring of surviving pairs: entry | tileX << 9 | tileY << 12
     int count;
+    int totalPairs;
 };
 
 // Rasterise up to 64 (triangle, tile) pairs, one pair per lane.
@@ -430,9 +447,9 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
 {
     const bool act = lane < npairs;
     const uint32_t q = sh.queue[wave][(head + lane) & (kQueueSize - 1)];
-    const int e = act ? (int)(q & 0xFFFFu) : 0;
-    const int tx = act ? (int)((q >> 16) & 15u) : 0;
-    const int tyl = act ? (int)(q >> 20) : 0;
+    const int e = act ? (int)(q & 511u) : 0;
+    const int tx = act ? (int)((q >> 9) & 7u) : 0;
+    const int tyl = act ? (int)((q >> 12) & 7u) : 0;
     const int X0 = (btx0 + tx) * 8, Y0 = (bty0 + tyl) * 8;
 
     // Each lane gathers its triangle's 64-byte record from L2 (the image's records are L2 resident).
@@ -461,7 +478,6 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     uint64_t m = act ? ~(((uint64_t)mhi << 32) | mlo) : 0ull;
     if (__ballot(m != 0) == 0) return;
 
-    if (p.dbg & 32) return;
     const uint32_t zx = q2.y, zy = q2.z;
     const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
     const uint32_t d0 = q2.w + zx * (uint32_t)X0 + zy * (uint32_t)Y0;   // depth at the tile origin
@@ -487,7 +503,9 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     }
 }
 
-template <bool PEEL, bool WRITE_DEPTH>
+// DBG = development instrumentation (per-workgroup phase timestamps and experiment switches); the
+// production instantiation carries none of it (the kernel sits at the 64-VGPR limit of 4 workgroups/CU).
+template <bool PEEL, bool WRITE_DEPTH, bool DBG>
 __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fine(const FineParams p)
 {
     __shared__ FineShared sh;
@@ -513,20 +531,25 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int vpwPad = (p.vp.vpw + 7) & ~7, vphPad = (p.vp.vph + 7) & ~7;
 
     unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
-    if (p.dbgbuf) tstamp[0] = wall_clock64();
+    unsigned long long dbgSurv = 0;
+    if (DBG && p.dbgbuf) tstamp[0] = wall_clock64();
     const unsigned long long kInit = ((unsigned long long)kDepthMax << 32) | 0xFFFFFFFFull;
 #pragma unroll
-    for (int t = 0; t < kBinTiles; t++) sh.key[wave][t][lane] = kInit;
+    for (int t = 0; t < kTilesPerWave; t++) sh.key[wave / kWavesPerRow][(wave % kWavesPerRow) * kTilesPerWave + t][lane] = kInit;
     if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
     __syncthreads();
 
     if (binTris > 0) {
         const int direct = p.instance ? p.T : p.ranges[2 * n + 1];
         const int pool   = min(p.poolCount[n], p.slots - p.poolBase);
-        // Index space scanned by the filter: [0, directPad) = direct slots (padded to 4),
-        // [directPad, directPad + pool) = pool slots.  Four consecutive slots per lane per step.
-        const int directPad = (direct + 3) & ~3;
-        const int total = directPad + pool;
+        // Index space scanned by the filter: [0, dlen) = the bin's range of direct slots (k_setup
+        // recorded the smallest and largest slot that touches the bin; meshes are spatially coherent
+        // in index order, so this is a small part of the image's triangles), [dlen, dlen + pool) =
+        // the clipper's pool slots.  Four consecutive slots per lane per step.
+        const int hiSlot = p.binHi[work];
+        const int scanLo = hiSlot ? ((0x7FFFFFFF - p.binLoInv[work]) & ~3) : 0;
+        const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
+        const int total = dlen + pool;
         const uint32_t* gbox = p.bbox + (size_t)n * p.slots;
         const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
 
@@ -540,14 +563,15 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             int idx = pos + lane * 4;
             uint4 b = make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
             if (idx < total) {
-                int slot = (idx < directPad) ? idx : p.poolBase + (idx - directPad);
-                b = *(const uint4*)(gbox + slot);
-                if (idx < directPad) {              // mask the padding beyond `direct`
-                    if (idx + 1 >= direct) b.y = kEmptyBox;
-                    if (idx + 2 >= direct) b.z = kEmptyBox;
-                    if (idx + 3 >= direct) b.w = kEmptyBox;
-                    if (idx >= direct) b.x = kEmptyBox;
+                if (idx < dlen) {                   // direct slots; mask the padding beyond `direct`
+                    const int slot = scanLo + idx;
+                    b = *(const uint4*)(gbox + slot);
+                    if (slot + 1 >= direct) b.y = kEmptyBox;
+                    if (slot + 2 >= direct) b.z = kEmptyBox;
+                    if (slot + 3 >= direct) b.w = kEmptyBox;
+                    if (slot >= direct) b.x = kEmptyBox;
                 } else {
+                    b = *(const uint4*)(gbox + p.poolBase + (idx - dlen));
                     int rem = total - idx;
                     if (rem < 2) b.y = kEmptyBox;
                     if (rem < 3) b.z = kEmptyBox;
@@ -582,7 +606,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                         if (hit && rank >= 0 && rank < can) {
                             int dst = base + rank;
                             int idx = scan + lane * 4 + sub;
-                            int slot = (idx < directPad) ? idx : p.poolBase + (idx - directPad);
+                            int slot = (idx < dlen) ? scanLo + idx : p.poolBase + (idx - dlen);
                             sh.slot[dst] = (uint32_t)slot;
                             sh.box[dst] = box;
                         }
@@ -596,44 +620,81 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 done = (scan >= total);
                 cur = nxt;
             }
-            unsigned long long tf0 = p.dbgbuf ? wall_clock64() : 0;
+            unsigned long long tf0 = (DBG && p.dbgbuf) ? wall_clock64() : 0;
             __syncthreads();
             const int cnt = min(sh.count, kListCap);
             found += cnt;
             // The bin is finished when every wave has scanned to the end or all its triangles are listed.
             const int allDone = __syncthreads_and((done || found >= binTris) ? 1 : 0);
-            unsigned long long tf1 = p.dbgbuf ? wall_clock64() : 0;
-            tstamp[1] += 1; tstamp[4] += cnt;
+            unsigned long long tf1 = (DBG && p.dbgbuf) ? wall_clock64() : 0;
+            if (DBG) { tstamp[1] += 1; tstamp[4] += cnt; }
 
             // ---- raster: every wave takes list chunks, queues their (triangle, tile) pairs and
             //      rasterises them 64 at a time into the shared key arrays (LDS atomics) -------------
-            if (!(p.dbg & 4)) {
+            // ---- raster: the list's (triangle, tile) pairs are numbered through a prefix sum of the
+            //      entries' pair counts; waves take 64 consecutive pair numbers at a time (lane = pair),
+            //      so work is balanced over all waves whatever the triangles' shapes, and rasterise
+            //      them into the shared key arrays (LDS atomics) ---------------------------------------
+            auto pair_box = [&](uint32_t box, int& x0, int& y0, int& nx, int& ny) {
+                const int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
+                x0 = max(txlo, btx0); y0 = max(tylo, bty0);
+                const int x1 = min(txhi, btx0 + kBinTiles - 1), y1 = min(tyhi, bty0 + kBinTiles - 1);
+                nx = max(x1 - x0 + 1, 0); ny = max(y1 - y0 + 1, 0);
+                if (nx == 0) ny = 0;
+            };
+            if (wave == 0) {
+                // exclusive scan of the pair counts: lane l owns entries [l*8, l*8+8)
+                constexpr int kPer = (kListCap + 63) / 64;
+                int local[kPer], sum = 0;
+#pragma unroll
+                for (int i = 0; i < kPer; i++) {
+                    const int j = lane * kPer + i;
+                    int x0, y0, nx = 0, ny = 0;
+                    if (j < cnt) pair_box(sh.box[j], x0, y0, nx, ny);
+                    local[i] = sum;
+                    sum += nx * ny;
+                }
+                int incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                const int base = incl - sum;
+#pragma unroll
+                for (int i = 0; i < kPer; i++) { const int j = lane * kPer + i; if (j <= cnt) sh.pfx[j] = (uint32_t)(base + local[i]); }
+                if (lane == 63) sh.totalPairs = incl;
+            }
+            __syncthreads();
+            if (!(DBG && (p.dbg & 4))) {
+                const int total = sh.totalPairs;
                 int head = 0, qn = 0;
-                for (int c = wave * 64; c < cnt; c += kFineWaves * 64) {
-                    int j = c + lane;
-                    uint32_t box = (j < cnt) ? sh.box[j] : kEmptyBox;
-                    int txlo = box & 255, tylo = (box >> 8) & 255, txhi = (box >> 16) & 255, tyhi = box >> 24;
-                    int x0 = max(txlo, btx0), x1 = min(txhi, btx0 + kBinTiles - 1);
-                    int y0 = max(tylo, bty0), y1 = min(tyhi, bty0 + kBinTiles - 1);
-                    int nx = max(x1 - x0 + 1, 0), ny = max(y1 - y0 + 1, 0);
-                    if (nx == 0) ny = 0;
-                    for (int ky = 0; ky < kBinTiles; ky++) {
-                        if (__ballot(ky < ny) == 0) break;
-                        for (int kx = 0; kx < kBinTiles; kx++) {
-                            const bool push = (kx < nx) & (ky < ny);
-                            uint64_t m = __ballot(push);
-                            if (m == 0) break;
-                            if (push) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
-                                (uint32_t)j | ((uint32_t)(x0 + kx - btx0) << 16) | ((uint32_t)(y0 + ky - bty0) << 20);
-                            qn += __popcll(m);
-                            if (qn >= 64) {
-                                __builtin_amdgcn_wave_barrier();
-                                raster_pairs<PEEL>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0);
-                                __builtin_amdgcn_wave_barrier();
-                                head = (head + 64) & (kQueueSize - 1);
-                                qn -= 64;
-                            }
-                        }
+                for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
+                    const int q = q0 + lane;
+                    const bool act = q < total;
+                    // entry j = the last one whose prefix is <= q (entries without pairs share a prefix
+                    // with their successor and are skipped by taking the last)
+                    int lo = 0, hi = cnt - 1;
+                    while (__ballot(lo < hi)) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (lo < hi) { if ((int)sh.pfx[mid] <= q) lo = mid; else hi = mid - 1; }
+                    }
+                    const int j = act ? lo : 0;
+                    int x0, y0, nx, ny;
+                    pair_box(sh.box[j], x0, y0, nx, ny);
+                    const int k = act ? q - (int)sh.pfx[j] : 0;
+                    const int ky = (nx > 1) ? (int)(((float)k + 0.5f) / (float)nx) : k;   // exact for k < 64, nx <= 8
+                    const int kx = k - ky * nx;
+                    const int tx = x0 + kx - btx0, tyl = y0 + ky - bty0;
+                    const bool keep = act;
+                    const uint64_t m = __ballot(keep);
+                    if (keep) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
+                        (uint16_t)((uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12));
+                    qn += __popcll(m);
+                    if (DBG) dbgSurv += __popcll(m);
+                    if (qn >= 64) {
+                        __builtin_amdgcn_wave_barrier();
+                        raster_pairs<PEEL>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0);
+                        __builtin_amdgcn_wave_barrier();
+                        head = (head + 64) & (kQueueSize - 1);
+                        qn -= 64;
                     }
                 }
                 if (qn > 0) {
@@ -642,7 +703,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if (p.dbgbuf) { unsigned long long tr = wall_clock64(); tstamp[2] += tf1 - tf0; tstamp[3] += tr - tf1; }
+            if (DBG && p.dbgbuf) { unsigned long long tr = wall_clock64(); if (p.dbg & 64) { tstamp[2] += (unsigned long long)sh.totalPairs; tstamp[3] += dbgSurv; dbgSurv = 0; } else { tstamp[2] += tf1 - tf0; tstamp[3] += tr - tf1; } }
             __syncthreads();
             if (allDone) break;
             if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
@@ -650,15 +711,17 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
     }
 
-    if (p.dbgbuf) tstamp[5] = wall_clock64();
+    if (DBG && p.dbgbuf) tstamp[5] = wall_clock64();
     // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w -----------
-    const int ty = bty0 + wave;
+    const int tileRow = wave / kWavesPerRow, tile0 = (wave % kWavesPerRow) * kTilesPerWave;
+    const int ty = bty0 + tileRow;
     const int Y = ty * 8 + ly;                  // viewport-local pixel row
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
 #pragma unroll 1
-    for (int t = 0; t < kBinTiles; t++) {
+    for (int tt = 0; tt < kTilesPerWave; tt++) {
+        const int t = tile0 + tt;
         const int X = (btx0 + t) * 8 + lx;
-        const unsigned long long key = sh.key[wave][t][lane];
+        const unsigned long long key = sh.key[tileRow][t][lane];
         if (WRITE_DEPTH) {
             if (X < vpwPad && Y < vphPad)
                 p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
@@ -667,8 +730,8 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         const int px = X + p.vp.offx, py = Y + p.vp.offy;
         const size_t pidx = ((size_t)n * p.H + py) * p.W + px;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), odb = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int triIdx = (p.dbg & 8) ? -1 : (int)(~(uint32_t)key) - 1;
-        bool write = !(p.dbg & 16);
+        const int triIdx = (DBG && (p.dbg & 8)) ? -1 : (int)(~(uint32_t)key) - 1;
+        bool write = !(DBG && (p.dbg & 16));
         if (triIdx >= 0 && triIdx < p.T) {
             int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
             if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) {
@@ -683,13 +746,15 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 float a0 = p1x * p2y - p1y * p2x;
                 float a1 = p2x * p0y - p2y * p0x;
                 float a2 = p0x * p1y - p0y * p1x;
-                float iw = 1.f / (a0 + a1 + a2);
+                // v_rcp_f32 (1 ulp) instead of IEEE division: three divisions per pixel are a sixth of
+                // this kernel's instruction count, and these outputs carry a 1e-5 tolerance.
+                float iw = __builtin_amdgcn_rcpf(a0 + a1 + a2);
                 float b0 = a0 * iw, b1 = a1 * iw;
                 float z = p0.z * a0 + p1.z * a1 + p2.z * a2;
                 float w = p0.w * a0 + p1.w * a1 + p2.w * a2;
-                float zw = z / w;
+                float zw = z * __builtin_amdgcn_rcpf(w);
                 b0 = __saturatef(b0); b1 = __saturatef(b1);
-                float bs = 1.f / fmaxf(b0 + b1, 1.f);
+                float bs = __builtin_amdgcn_rcpf(fmaxf(b0 + b1, 1.f));
                 b0 *= bs; b1 *= bs;
                 zw = fmaxf(fminf(zw, 1.f), -1.f);
                 o = make_float4(b0, b1, zw, triidx_to_float(triIdx + 1));
@@ -708,7 +773,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             ((float4*)p.out_db)[pidx] = odb;
         }
     }
-    if (p.dbgbuf && lane == 0) {
+    if (DBG && p.dbgbuf && lane == 0) {
         unsigned long long* d = p.dbgbuf + ((size_t)item * kFineWaves + wave) * 8;
         d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3]; d[4] = tstamp[4]; d[5] = tstamp[5]; d[6] = wall_clock64(); d[7] = (unsigned long long)work;
     }
@@ -936,7 +1001,7 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 // Host side
 // ---------------------------------------------------------------------------------
 
-struct ScratchLayout { size_t rec, bbox, pool, binCount, order, total; int slots, poolBase, maxBins; };
+struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, order, total; int slots, poolBase, maxBins; };
 
 static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
 {
@@ -954,7 +1019,9 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
     L.pool  = align_up(L.bbox + (size_t)N * L.slots * 4, 256);
     // pool counters and per-bin counts are adjacent: one memset clears both
     L.binCount = L.pool + (size_t)N * 4;
-    L.order = align_up(L.binCount + (size_t)N * L.maxBins * 4, 256);
+    L.binHi = L.binCount + (size_t)N * L.maxBins * 4;
+    L.binLoInv = L.binHi + (size_t)N * L.maxBins * 4;
+    L.order = align_up(L.binLoInv + (size_t)N * L.maxBins * 4, 256);
     L.total = align_up(L.order + (size_t)N * L.maxBins * 4, 256);
     return L;
 }
@@ -993,6 +1060,8 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
     uint32_t* bbox = (uint32_t*)(sb + L.bbox);
     int* pool = (int*)(sb + L.pool);
     int* binCount = (int*)(sb + L.binCount);
+    int* binHi = (int*)(sb + L.binHi);
+    int* binLoInv = (int*)(sb + L.binLoInv);
     int* order = (int*)(sb + L.order);
 
     const int Hp = (H + 7) & ~7, Wp = (W + 7) & ~7;
@@ -1022,7 +1091,9 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         const int binsY = (vphPad / 8 + kBinTiles - 1) / kBinTiles;
         const int totalBins = N * binsX * binsY;
         sp.binCount = binCount; sp.binsX = binsX; sp.binsY = binsY;
-        NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4 + (size_t)totalBins * 4, stream));
+        sp.binHi = binHi; sp.binLoInv = binLoInv;
+        // pool cursors, bin counts and bin slot ranges are adjacent: one memset clears them all
+        NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4 + 3 * (size_t)N * L.maxBins * 4, stream));
         {
             ProfileScope ps("raster_setup", stream);
             hipLaunchKernelGGL(k_setup, dim3((max_tri + 255) / 256, N, 1), dim3(256), 0, stream, sp);
@@ -1039,7 +1110,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.instance = sp.instance; fp.N = N; fp.V = V; fp.T = T; fp.maxTri = max_tri; fp.poolBase = L.poolBase; fp.slots = L.slots;
         fp.W = W; fp.H = H; fp.Wp = Wp; fp.Hp = Hp; fp.vp = vp;
         fp.binsX = binsX; fp.binsY = binsY; fp.totalBins = totalBins;
-        fp.binCount = binCount; fp.order = order;
+        fp.binCount = binCount; fp.order = order; fp.binHi = binHi; fp.binLoInv = binLoInv;
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
@@ -1048,10 +1119,16 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         const int grid = ((totalBins + 7) / 8) * 8;
         {
             ProfileScope ps("raster_fine", stream);
-            if (peel_depth && depth_out)       hipLaunchKernelGGL((k_fine<true, true>),   dim3(grid), dim3(kFineThreads), 0, stream, fp);
-            else if (peel_depth)               hipLaunchKernelGGL((k_fine<true, false>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);
-            else if (depth_out)                hipLaunchKernelGGL((k_fine<false, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);
-            else                               hipLaunchKernelGGL((k_fine<false, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);
+#define NVDR_FINE(PEEL, WD)                                                                                           \
+    do {                                                                                                              \
+        if (dbgMode) hipLaunchKernelGGL((k_fine<PEEL, WD, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);   \
+        else         hipLaunchKernelGGL((k_fine<PEEL, WD, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);   \
+    } while (0)
+            const bool dbgMode = fp.dbgbuf != nullptr || (fp.dbg & (4 | 8 | 16)) != 0;
+            if (peel_depth && depth_out)       NVDR_FINE(true, true);
+            else if (peel_depth)               NVDR_FINE(true, false);
+            else if (depth_out)                NVDR_FINE(false, true);
+            else                               NVDR_FINE(false, false);
         }
         NVDR_LAUNCH_CHECK();
     }

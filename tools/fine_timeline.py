@@ -17,12 +17,13 @@ for _ in range(3):
     dr.rasterize(ctx, pos, tri, (512, 512))
 torch.cuda.synchronize()
 nwg = N * 64
-buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
+WAVES = 8
+buf = torch.zeros(nwg * WAVES * 8, dtype=torch.int64, device=dev)
 lib.nvdr_debug_buffer(buf.data_ptr())
 dr.rasterize(ctx, pos, tri, (512, 512))
 torch.cuda.synchronize()
 lib.nvdr_debug_buffer(None)
-d = buf.cpu().numpy().reshape(nwg, 8, 8).astype(np.float64)
+d = buf.cpu().numpy().reshape(nwg, WAVES, 8).astype(np.float64)
 t0 = d[:, :, 0].min()
 start = (d[:, 0, 0] - t0) / 100.0          # wall_clock64 = 100 MHz -> us
 end = (d[:, :, 6].max(1) - t0) / 100.0
