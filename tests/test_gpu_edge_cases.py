@@ -1,0 +1,148 @@
+"""GPU edge cases: inputs the reference guards against explicitly (corrupt indices, empty ranges,
+degenerate and non-finite geometry, zero gradients) and size extremes.  Checked against the oracle
+wherever it defines the result."""
+import numpy as np
+import pytest
+import torch
+
+from nvdiffrast_amd.utils import m10k_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _ids_equal(dr, oracle, pos, tri, res, ranges=None):
+    ctx = dr.RasterizeCudaContext()
+    r, rdb = dr.rasterize(ctx, _t(pos), _t(tri), res, ranges=None if ranges is None else torch.from_numpy(ranges))
+    ro, rdbo = oracle.rasterize(pos, tri, res, ranges=ranges)
+    r = r.cpu().numpy()
+    assert (r[..., 3] != ro[..., 3]).sum() == 0
+    ok = np.isfinite(ro[..., :3]).all(-1) & np.isfinite(r[..., :3]).all(-1)   # non-finite geometry: the NaN pattern is not specified
+    assert np.abs(r[..., :3][ok] - ro[..., :3][ok]).max(initial=0.0) <= 1e-5
+    return r, ro
+
+
+def test_empty_and_partial_ranges(dr, oracle):
+    b = m10k_batch(1, seed=3, nx=20, ny=10)
+    pos = b["pos"][0]
+    T = b["tri"].shape[0]
+    ranges = np.array([[0, 0], [5, 1], [T - 3, 3], [0, T]], np.int32)
+    r, ro = _ids_equal(dr, oracle, pos, b["tri"], (64, 64), ranges)
+    assert (r[0, ..., 3] == 0).all()                      # zero triangles -> background only
+    assert set(np.unique(r[1, ..., 3])) <= {0.0, 6.0}     # ids stay global triangle numbers (+1)
+
+
+def test_corrupt_indices_are_skipped(dr, oracle):
+    b = m10k_batch(2, seed=4, nx=16, ny=8)
+    tri = b["tri"].copy()
+    V = b["pos"].shape[1]
+    tri[3] = [0, V, 1]; tri[10] = [-1, 2, 3]; tri[11] = [5, 5, 5]; tri[12] = [7, 8, 7]
+    r, ro = _ids_equal(dr, oracle, b["pos"], tri, (96, 80))
+    assert not np.isin(r[..., 3], [4.0, 11.0, 12.0, 13.0]).any()
+    # interpolate / antialias tolerate the same table (their own index guards)
+    out, _ = dr.interpolate(_t(b["attr"]), _t(r), _t(tri))
+    oo, _ = oracle.interpolate(b["attr"], r, tri)
+    assert np.abs(out.cpu().numpy() - oo).max() <= 1e-5
+    col = np.random.default_rng(0).uniform(size=r.shape[:3] + (3,)).astype(np.float32)
+    aa = dr.antialias(_t(col), _t(r), _t(b["pos"]), _t(tri))
+    assert np.abs(aa.cpu().numpy() - oracle.antialias(col, r, b["pos"], tri)).max() <= 1e-5
+
+
+def test_degenerate_and_nonfinite_geometry(dr, oracle):
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(-1, 1, size=(1, 60, 4)).astype(np.float32)
+    pos[..., 3] = rng.uniform(0.5, 2.0, size=(1, 60))
+    pos[0, 3] = pos[0, 4]                                   # zero-area triangles
+    pos[0, 6, 3] = 0.0                                      # w = 0
+    pos[0, 9, 0] = np.nan
+    pos[0, 12, 1] = np.inf
+    pos[0, 15, 3] = -1.0                                    # behind the eye
+    pos[0, 18:21, :2] *= 1e4                                # far outside the viewport
+    tri = np.arange(60, dtype=np.int32).reshape(20, 3)
+    r, ro = _ids_equal(dr, oracle, pos, tri, (40, 40))
+    assert np.isfinite(r[..., 3]).all()
+    # backward on the same scene must not produce NaN where the oracle does not
+    ctx = dr.RasterizeCudaContext()
+    p = _t(pos).requires_grad_(True)
+    rr, rdb = dr.rasterize(ctx, p, _t(tri), (40, 40))
+    G = rng.normal(size=rr.shape).astype(np.float32)
+    (rr * _t(G)).sum().backward()
+    go = oracle.rasterize_grad(pos, tri, ro, G, ddb=np.zeros_like(G))
+    g = p.grad.cpu().numpy()
+    fin = np.isfinite(go) & np.isfinite(g)
+    assert fin.mean() > 0.8
+    assert np.abs(g[fin] - go[fin]).max() <= 1e-5 * max(1.0, np.abs(go[fin]).max())
+
+
+def test_zero_upstream_gradients(dr):
+    b = m10k_batch(1, seed=6, nx=12, ny=6)
+    pos = _t(b["pos"]).requires_grad_(True)
+    attr = _t(b["attr"]).requires_grad_(True)
+    tri = _t(b["tri"])
+    ctx = dr.RasterizeCudaContext()
+    rast, rast_db = dr.rasterize(ctx, pos, tri, (32, 32))
+    out, _ = dr.interpolate(attr, rast, tri)
+    (out * 0.0).sum().backward()
+    assert float(pos.grad.abs().max()) == 0.0 and float(attr.grad.abs().max()) == 0.0
+    tex = torch.rand(1, 8, 8, 3, device="cuda", requires_grad=True)
+    uv = torch.rand(1, 5, 5, 2, device="cuda", requires_grad=True)
+    da = (torch.rand(1, 5, 5, 4, device="cuda") * 0.1).requires_grad_(True)
+    o = dr.texture(tex, uv, da)
+    (o * 0.0).sum().backward()
+    assert float(tex.grad.abs().max()) == 0.0 and float(uv.grad.abs().max()) == 0.0 and float(da.grad.abs().max()) == 0.0
+
+
+def test_size_extremes(dr, oracle):
+    tri = np.array([[0, 1, 2]], np.int32)
+    pos = np.array([[[-1, -1, 0, 1], [3, -1, 0, 1], [-1, 3, 0, 1]]], np.float32)      # covers the whole viewport
+    for res in [(1, 1), (1, 7), (9, 1), (3, 2048), (2050, 5)]:
+        r, ro = _ids_equal(dr, oracle, pos, tri, res)
+        assert (r[..., 3] == 1).all()
+    # many images, one pixel each
+    posN = np.repeat(pos, 300, 0)
+    r, ro = _ids_equal(dr, oracle, posN, tri, (1, 1))
+    assert r.shape == (300, 1, 1, 4)
+    # a single triangle index table entry referencing the same vertex thrice renders nothing
+    r, ro = _ids_equal(dr, oracle, pos, np.array([[1, 1, 1]], np.int32), (8, 8))
+    assert (r[..., 3] == 0).all()
+
+
+def test_many_attributes_and_diff_list(dr, oracle):
+    b = m10k_batch(2, seed=8, nx=16, ny=8, attrs=37)
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], (48, 48))
+    lst = [0, -1, 5, 36, 100, -40]                       # out-of-range entries yield zeros (interpolate.cu:102-106)
+    attr = _t(b["attr"]).requires_grad_(True)
+    out, da = dr.interpolate(attr, _t(ro), _t(b["tri"]), rast_db=_t(rdbo), diff_attrs=lst)
+    oo, dao = oracle.interpolate(b["attr"], ro, b["tri"], rast_db=rdbo, diff_attrs=lst)
+    assert np.abs(out.detach().cpu().numpy() - oo).max() <= 1e-5
+    assert np.abs(da.detach().cpu().numpy() - dao).max() <= 1e-5 * max(1.0, np.abs(dao).max())
+    rng = np.random.default_rng(9)
+    G = rng.normal(size=oo.shape).astype(np.float32); Gda = rng.normal(size=dao.shape).astype(np.float32)
+    ((out * _t(G)).sum() + (da * _t(Gda)).sum()).backward()
+    ga, _, _ = oracle.interpolate_grad(b["attr"], ro, b["tri"], G, rast_db=rdbo, dda=Gda, diff_attrs=lst)
+    assert np.abs(attr.grad.cpu().numpy() - ga).max() <= 1e-5 * max(1.0, np.abs(ga).max())
+    with pytest.raises(RuntimeError, match="too many entries in diff_attrs"):
+        dr.interpolate(attr, _t(ro), _t(b["tri"]), rast_db=_t(rdbo), diff_attrs=list(range(33)))
+
+
+def test_error_messages_match_the_reference(dr):
+    ctx = dr.RasterizeCudaContext()
+    pos = torch.zeros(1, 3, 4, device="cuda"); tri = torch.zeros(1, 3, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match=r"resolution must be \[>0, >0\]"):
+        dr.rasterize(ctx, pos, tri, (0, 8))
+    with pytest.raises(RuntimeError, match="must be int32 tensors"):
+        dr.rasterize(ctx, pos, tri.long(), (8, 8))
+    with pytest.raises(RuntimeError, match=r"instance mode - pos must have shape \[>0, >0, 4\]"):
+        dr.rasterize(ctx, torch.zeros(1, 3, 3, device="cuda"), tri, (8, 8))
+    with pytest.raises(RuntimeError, match="must be contiguous tensors"):
+        dr.rasterize(ctx, torch.zeros(1, 4, 3, device="cuda").transpose(1, 2), tri, (8, 8))
+    with pytest.raises(RuntimeError, match=r"range mode - ranges must have shape \[>0, 2\]"):
+        dr.rasterize(ctx, torch.zeros(3, 4, device="cuda"), tri, (8, 8))
+    with dr.DepthPeeler(ctx, pos, tri, (8, 8)) as peeler:
+        assert isinstance(dr.rasterize(ctx, pos, tri, (8, 8)), RuntimeError)      # returned, not raised (ops.py:131-132)
+        with pytest.raises(RuntimeError, match="multiple depth peelers"):
+            dr.DepthPeeler(ctx, pos, tri, (8, 8)).__enter__()
+        peeler.rasterize_next_layer()
