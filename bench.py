@@ -164,47 +164,49 @@ def main():
                     "traffic": traffic, "kernel_avg_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes"]}
         path_bytes = (112 + 8 * ATTRS) * P                           # 144 B/pixel at A = 4
 
-        # ---- parity of this workload against the oracle (checker only) ---------------------
-        import oracle
-        ns = 2
-        ro, _ = oracle.rasterize(scene["pos"][:ns], scene["tri"], (RES, RES))
-        Gs = G[:ns].cpu().numpy()
-        ga_o, gr_o, _ = oracle.interpolate_grad(scene["attr"], ro, scene["tri"], Gs)
-        gp_o = oracle.rasterize_grad(scene["pos"][:ns], scene["tri"], ro, gr_o)
-        # device gradients for the same two items
-        pos_s = torch.from_numpy(scene["pos"][:ns]).to(dev).requires_grad_(True)
-        attr_s = torch.from_numpy(scene["attr"]).to(dev).requires_grad_(True)
-        r_s, _ = dr.rasterize(ctx, pos_s, tri, (RES, RES))
-        o_s, _ = dr.interpolate(attr_s, r_s, tri)
-        torch.autograd.backward(o_s, G[:ns])
-        parity = {
-            "items": ns,
-            "tri_id_mismatches": int((r_s[..., 3].detach().cpu().numpy() != ro[..., 3]).sum()),
-            "bary_max_abs_err": float(np.abs(r_s[..., :3].detach().cpu().numpy() - ro[..., :3]).max()),
-            "g_attr_max_abs_err": float(np.abs(attr_s.grad.cpu().numpy() - ga_o).max()),
-            "g_pos_max_abs_err": float(np.abs(pos_s.grad.cpu().numpy() - gp_o).max()),
-            "g_pos_max_abs": float(np.abs(gp_o).max()),
-        }
+        # ---- parity of this workload against the oracle (checker only; single-GPU runs) ----
+        parity = cpu = None
+        run_checks = (world == 1)
+        if run_checks:
+            import oracle
+            ns = 2
+            ro, _ = oracle.rasterize(scene["pos"][:ns], scene["tri"], (RES, RES))
+            Gs = G[:ns].cpu().numpy()
+            ga_o, gr_o, _ = oracle.interpolate_grad(scene["attr"], ro, scene["tri"], Gs)
+            gp_o = oracle.rasterize_grad(scene["pos"][:ns], scene["tri"], ro, gr_o)
+            # device gradients for the same two items
+            pos_s = torch.from_numpy(scene["pos"][:ns]).to(dev).requires_grad_(True)
+            attr_s = torch.from_numpy(scene["attr"]).to(dev).requires_grad_(True)
+            r_s, _ = dr.rasterize(ctx, pos_s, tri, (RES, RES))
+            o_s, _ = dr.interpolate(attr_s, r_s, tri)
+            torch.autograd.backward(o_s, G[:ns])
+            parity = {
+                "items": ns,
+                "tri_id_mismatches": int((r_s[..., 3].detach().cpu().numpy() != ro[..., 3]).sum()),
+                "bary_max_abs_err": float(np.abs(r_s[..., :3].detach().cpu().numpy() - ro[..., :3]).max()),
+                "g_attr_max_abs_err": float(np.abs(attr_s.grad.cpu().numpy() - ga_o).max()),
+                "g_pos_max_abs_err": float(np.abs(pos_s.grad.cpu().numpy() - gp_o).max()),
+                "g_pos_max_abs": float(np.abs(gp_o).max()),
+            }
 
-        # ---- CPU baseline: the oracle on this host's cores, bounded sample -----------------
-        cpu = None
-        if not args.no_cpu_baseline:
-            nc = max(1, min(args.cpu_items, N))
-            pc, tc, ac = scene["pos"][:nc], scene["tri"], scene["attr"]
-            Gc = G[:nc].cpu().numpy()
-            times = []
-            for rep in range(5):
-                t1 = time.perf_counter()
-                r_c, _ = oracle.rasterize(pc, tc, (RES, RES))
-                o_c, _ = oracle.interpolate(ac, r_c, tc)
-                ga, gr, _ = oracle.interpolate_grad(ac, r_c, tc, Gc)
-                gp = oracle.rasterize_grad(pc, tc, r_c, gr)
-                times.append(time.perf_counter() - t1)
-            tmed = sorted(times)[2]
-            cpu = {"value": round(nc * RES * RES / tmed / 1e6, 2), "unit": "Mpixels/s", "cores": oracle.num_threads(),
-                   "kind": "port",
-                   "sample": f"{nc} of the {N} items of the same batch, fwd+bwd, median of 5 (reference has no CPU path; "
-                             f"this is the repo's C/OpenMP restatement), host cpu_count={os.cpu_count()}"}
+            # ---- CPU baseline: the oracle on this host's cores, bounded sample -----------------
+            if not args.no_cpu_baseline:
+                nc = max(1, min(args.cpu_items, N))
+                pc, tc, ac = scene["pos"][:nc], scene["tri"], scene["attr"]
+                Gc = G[:nc].cpu().numpy()
+                times = []
+                for rep in range(5):
+                    t1 = time.perf_counter()
+                    r_c, _ = oracle.rasterize(pc, tc, (RES, RES))
+                    o_c, _ = oracle.interpolate(ac, r_c, tc)
+                    ga, gr, _ = oracle.interpolate_grad(ac, r_c, tc, Gc)
+                    gp = oracle.rasterize_grad(pc, tc, r_c, gr)
+                    times.append(time.perf_counter() - t1)
+                tmed = sorted(times)[2]
+                cpu = {"value": round(nc * RES * RES / tmed / 1e6, 2), "unit": "Mpixels/s", "cores": oracle.num_threads(),
+                       "kind": "port",
+                       "sample": f"{nc} of the {N} items of the same batch, fwd+bwd, median of 5 (reference has no CPU path; "
+                                 f"this is the repo's C/OpenMP restatement), host cpu_count={os.cpu_count()}"}
 
         result = {
             "metric": "Mpixels/s rasterize+interpolate fwd+bwd @512^2 batch64",

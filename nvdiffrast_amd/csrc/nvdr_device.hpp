@@ -170,6 +170,22 @@ struct FixedScale {
     }
 };
 
+// 32-bit variant for accumulators with few terms per cell (texel patches): x -> round(x * 2^s) with
+// s = 20 - e (M < 2^(e+1) the largest summand), so one summand stays below 2^21, a pre-summed run of 16
+// below 2^25 and a cell holding <= 512 summands below 2^30.  Resolution 2^-21 of M (rounding error
+// <= 2^-22 M per summand: the ulp scale of an f32 sum of that size).
+struct FixedScale32 {
+    float scale, inv;
+    __device__ __forceinline__ explicit FixedScale32(uint32_t max_bits) {
+        int e = (int)(max_bits >> 23) - 127;                       // M < 2^(e+1)
+        e = max(e, -100);                                            // keep 2^(20-e) finite for denormal maxima
+        scale = __int_as_float((127 + 20 - e) << 23);
+        inv   = __int_as_float((127 - 20 + e) << 23);
+    }
+    __device__ __forceinline__ int to_fixed(float x) const { return __float2int_rn(x * scale); }
+    __device__ __forceinline__ float to_float(int t) const { return (float)t * inv; }
+};
+
 // Segmented inclusive scan over runs of equal `key` among consecutive active lanes, limited to
 // the 16-lane DPP rows (a run that crosses a row boundary simply yields two totals).  After
 // scan(v) the last lane of every run (`tail`) holds the run's sum.

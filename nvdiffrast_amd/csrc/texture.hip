@@ -511,21 +511,23 @@ __global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
 // ---- backward (texture_kernel.cu:905-1140) -------------------------------------------------
 
 // Texel-gradient accumulator of one workgroup: an LDS open-addressing table of 8x2-texel patches
-// keyed by (level, patch x, patch y), each patch holding 16 texels x C channels of 64-bit fixed-point
+// keyed by (level, patch x, patch y), each patch holding 16 texels x C channels of 32-bit fixed-point
 // sums (nvdr_device.hpp: LDS integer atomics are ~30x cheaper than ds_add_f32, and a global atomic
-// costs one memory transaction per touched cache line).  Every tap of the workgroup's 16x16 pixels is
+// costs one memory transaction per touched cache line).  32 bits (resolution 2^-22 of the block's
+// largest |dy|, i.e. the ulp of an f32 sum of that size) instead of the vertex tables' 64 keep the
+// table at 25 KB so that six workgroups fit a CU.  Every tap of the workgroup's 16x16 pixels is
 // added here; at the end each patch row is flushed by consecutive lanes, so one atomic instruction
 // covers a few whole lines instead of 64 scattered ones, and pixels that hit the same texel (e.g. a
 // constant-uv background) cost one global atomic per workgroup instead of one per pixel.
 // The fixed-point scale comes from the block's largest |dy| (every tap weight is in [0,1]).
 struct PatchTable {
     unsigned long long* keys;     // [groups]  0 = empty
-    unsigned long long* vals;     // [groups * 16 * C]
+    int* vals;                    // [groups * 16 * C] 32-bit fixed-point sums
     int groups, C;
 
     __device__ __forceinline__ void clear(int tid, int nthreads) {
         for (int i = tid; i < groups; i += nthreads) keys[i] = 0ull;
-        for (int i = tid; i < groups * 16 * C; i += nthreads) vals[i] = 0ull;
+        for (int i = tid; i < groups * 16 * C; i += nthreads) vals[i] = 0;
     }
     static __device__ __forceinline__ unsigned long long key_of(int level, int x, int y) {
         return ((unsigned long long)(level + 1) << 58) | ((unsigned long long)(unsigned)(y >> 1) << 29) | (unsigned long long)(unsigned)(x >> 3);
@@ -548,12 +550,12 @@ struct PatchTable {
 };
 
 template <int FILTER, bool BIAS_ONLY, bool CUBE>
-__global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
+__global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     const int C = p.channels;
-    PatchTable tab{(unsigned long long*)s_mem, (unsigned long long*)s_mem + groups, groups, C};
-    uint32_t* s_max = (uint32_t*)((unsigned long long*)s_mem + groups + (size_t)groups * 16 * C);
+    PatchTable tab{(unsigned long long*)s_mem, (int*)((unsigned long long*)s_mem + groups), groups, C};
+    uint32_t* s_max = (uint32_t*)(tab.vals + (size_t)groups * 16 * C);
     int px = 0, py = 0, pz = 0; bool inside;
     if (!tex_pixel(p, px, py, pz, inside)) return;
     if (groups > 0 && !(p.dbg & 2048)) tab.clear(threadIdx.x, 256);
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
     const uint32_t maxBits = *s_max;
     if (maxBits == 0u) return;                                   // nobody has anything to scatter
     const bool direct = (groups == 0) || maxBits >= 0x7F800000u; // no table / inf or NaN present: plain f32 atomics
-    const FixedScale fs(direct ? 0x3F800000u : maxBits);
+    const FixedScale32 fs(direct ? 0x3F800000u : maxBits);
 
     // One tap's contribution: LDS table when it has a slot, global atomic otherwise.
     const bool noScatter = p.dbg & 512;
@@ -757,8 +759,8 @@ __global__ __launch_bounds__(256) void k_tex_grad(const TexParams p, int groups)
         const int g = i / perGroup;
         const unsigned long long key = tab.keys[g];
         if (key == 0ull) continue;
-        const unsigned long long t = tab.vals[i];
-        if (t == 0ull) continue;
+        const int t = tab.vals[i];
+        if (t == 0) continue;
         const int r = i - g * perGroup;
         const int tx = r / C, c = r - tx * C;
         const int level = (int)(key >> 58) - 1;
@@ -1018,12 +1020,13 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     NVDR_REQUIRE(!(filter_mode == TEX_LML && p.bias) || g_mip_level_bias, "texture_grad: g_mip_level_bias missing");
     const dim3 grid = tex_grid(p);
     const bool bo = (filter_mode >= TEX_LMN) && !p.uvDA;
-    // LDS patch table: as many power-of-two patches of 16 texels as fit in 64 KiB (at most 512);
+    // LDS patch table: as many power-of-two patches of 16 texels as fit in 26 KiB (at most 512), so that
+    // six workgroups share a CU (the kernel is latency bound: occupancy matters more than table size);
     // none (direct atomics) when even 16 patches do not fit.
     int groups = 512;
-    while (groups >= 16 && (size_t)groups * (8 + 128 * (size_t)C) + 16 > 64 * 1024) groups >>= 1;
+    while (groups >= 16 && (size_t)groups * (8 + 64 * (size_t)C) + 16 > 26 * 1024) groups >>= 1;
     if (groups < 16 || (debug_flags() & 256)) groups = 0;
-    const size_t lds = (size_t)groups * (8 + 128 * (size_t)C) + 16;
+    const size_t lds = (size_t)groups * (8 + 64 * (size_t)C) + 16;
     {
         ProfileScope ps("tex_grad", stream);
 #define NVDR_TEX_GRAD(FILTER, BO)                                                                              \
