@@ -194,7 +194,7 @@ __device__ bool snap_cull_setup(const Viewport& vp, const float (*v)[4], SubTri&
 // Record layout (4 x uint4):
 //   q0 = {A0, B0, C0, A1}   q1 = {B1, C1, A2, B2}   q2 = {C2, zx, zy, zb}   q3 = {id, aabb, 0, 0}
 // with E_e(X,Y) = C_e + X*A_e + Y*B_e >= 0  <=>  pixel (X,Y) is inside edge e.
-__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id, int* s_hist)
+__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id, int* s_hist, uint4* stage)
 {
     const Viewport& vp = p.vp;
     int bx = (vp.vpw - 1) << (kSpLog2 - 1);
@@ -228,7 +228,9 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
         B[e] = (uint32_t)(16 * dx);
         C[e] = (uint32_t)(s.px[a] + bx) * (uint32_t)dy - (uint32_t)(s.py[a] + by) * (uint32_t)dx - excl;
     }
-    uint4* r = p.rec + so * 4;
+    // Direct slots go through the block's LDS stage and leave as whole 1 KiB rows (k_setup); pool slots
+    // (clipper output, rare) are written in place.
+    uint4* r = stage ? stage : p.rec + so * 4;
     r[0] = make_uint4(A[0], B[0], C[0], A[1]);
     r[1] = make_uint4(B[1], C[1], A[2], B[2]);
     r[2] = make_uint4(C[2], s.zx, s.zy, s.zb);
@@ -267,7 +269,7 @@ __device__ int clip_poly_plane(float* out, const float* in, int n_in, float f0, 
 
 // Slow path, TriangleSetup.inl:355-434 + Util.inl:134-160.  Kept out of line so the common
 // path stays small.
-__device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist)
+__device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist, uint4* stage)
 {
 #pragma clang fp contract(off)
     float d1[4], d2[4], bary[18], tmp[18];
@@ -300,15 +302,15 @@ __device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot
     }
 
     if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return; }
-    emit_record(p, n, slot0, st[0], id, s_hist);
+    emit_record(p, n, slot0, st[0], id, s_hist, stage);
     if (ns > 1) {
         int base = atomicAdd(&p.poolCount[n], ns - 1);       // cannot exceed slots - poolBase by construction
         for (int k = 1; k < ns; k++)
-            emit_record(p, n, p.poolBase + base + k - 1, st[k], id, s_hist);
+            emit_record(p, n, p.poolBase + base + k - 1, st[k], id, s_hist, nullptr);
     }
 }
 
-__device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, int* s_hist)
+__device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage)
 {
 #pragma clang fp contract(off)
     int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
@@ -345,10 +347,10 @@ __device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, in
 
     if (inside) {                                                                    // :329-352
         SubTri st;
-        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist);
+        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist, stage);
         else p.bbox[so] = kEmptyBox;
     } else {
-        setup_clipped(p, n, i, v, t + 1, s_hist);
+        setup_clipped(p, n, i, v, t + 1, s_hist, stage);
     }
 }
 
@@ -360,8 +362,25 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
     for (int b = threadIdx.x; b < nb; b += 256) { s_hist[b] = 0; s_hist[kMaxBins + b] = 0; s_hist[2 * kMaxBins + b] = 0; }
     __syncthreads();
     const int n = blockIdx.y;
-    setup_one(p, n, blockIdx.x * 256 + threadIdx.x, s_hist);
+    // Records are staged in LDS (one 64-byte record per thread) and written out as contiguous 1 KiB
+    // rows: the L2 is write-through, so four 16-byte stores at a 64-byte stride per lane would reach
+    // memory as four partial-line writes each (measured: 4x the bytes).  Slots of culled triangles
+    // receive whatever the stage holds; their AABB marks them empty.
+    __shared__ uint4 s_rec[256 * 4];
+    setup_one(p, n, blockIdx.x * 256 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4);
     __syncthreads();
+    {
+        const int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int slot0 = blockIdx.x * 256 + wave * 64;
+        uint4* dst = p.rec + ((size_t)n * p.slots + slot0) * 4;
+        const uint4* src = s_rec + wave * 64 * 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = k * 64 + lane;                       // 16-byte chunk inside the wave's 4 KiB
+            if (slot0 + (q >> 2) < cnt) dst[q] = src[q];
+        }
+    }
     // One global atomic per non-empty bin per block (instead of one per triangle).
     for (int b = threadIdx.x; b < nb; b += 256) {
         int c = s_hist[b];
