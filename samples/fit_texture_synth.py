@@ -8,7 +8,7 @@ texture being learned -- and takes an Adam step on the L2 image difference.  The
     rasterize -> interpolate(uv, diff_attrs='all') -> texture(linear-mipmap-linear) -> antialias
 so every forward and backward kernel of the path runs every iteration.
 
-    python samples/fit_texture_synth.py [--iters 200] [--res 256] [--ref-res 1024] [--tex 512]
+    python samples/fit_texture_synth.py [--iters 200] [--res 256] [--ref-res 1024] [--tex 512] [--graph]
 Prints one JSON line: first/last loss, texture RMSE before/after, iterations per second.
 """
 import argparse
@@ -59,7 +59,7 @@ def render(ctx, mvp, pos, tri, uv, tex, res, topo):
     return dr.antialias(color, rast, clip, tri, topology_hash=topo)
 
 
-def fit(iters=200, res=256, ref_res=1024, tex_size=512, seed=0, lr=1e-2, device="cuda"):
+def fit(iters=200, res=256, ref_res=1024, tex_size=512, seed=0, lr=1e-2, device="cuda", graph=False):
     dev = torch.device(device)
     pos_np, uv_np, tri_np = uv_sphere()
     pos = torch.from_numpy(pos_np).to(dev)
@@ -73,25 +73,55 @@ def fit(iters=200, res=256, ref_res=1024, tex_size=512, seed=0, lr=1e-2, device=
     proj = perspective(x=0.4, n=1.0, f=20.0) @ translation(0, 0, -3.5)
     rng = np.random.default_rng(seed)
     rmse0 = float(torch.sqrt(torch.mean((tex_opt.detach() - tex_true) ** 2)))
-    losses = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(iters):
-        mvp = torch.from_numpy((proj @ random_pose(rng, 0.0)).astype(np.float32)).to(dev)
+    mvp = torch.zeros(4, 4, device=dev)
+    loss_buf = torch.zeros((), device=dev)
+
+    def one_iteration():
         with torch.no_grad():
             ref = render(ctx, mvp, pos, tri, uv, tex_true, ref_res, topo)
             k = ref_res // res
             ref = ref.reshape(1, res, k, res, k, 3).mean((2, 4))
         img = render(ctx, mvp, pos, tri, uv, tex_opt, res, topo)
         loss = torch.mean((img - ref) ** 2)
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad(set_to_none=False)
         loss.backward()
         opt.step()
-        losses.append(float(loss.detach()))
+        loss_buf.copy_(loss.detach())
+
+    def new_view():
+        mvp.copy_(torch.from_numpy((proj @ random_pose(rng, 0.0)).astype(np.float32)), non_blocking=False)
+
+    g = None
+    if graph:
+        # Every op of the path is asynchronous and allocation-free at the C-ABI level, so a whole
+        # iteration (two renders, backward, Adam) captures into one hipGraph; only the view matrix
+        # changes between replays.  Launch-bound at these sizes: see the printed it/s with and without.
+        opt = torch.optim.Adam([tex_opt], lr=lr, capturable=True)
+        new_view()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                one_iteration()                                   # warm-up: allocations, scratch growth
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            one_iteration()
+    losses = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(iters):
+        new_view()
+        if g is not None:
+            g.replay()
+        else:
+            one_iteration()
+        if it < 5 or it >= iters - 5:
+            losses.append(float(loss_buf))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rmse1 = float(torch.sqrt(torch.mean((tex_opt.detach() - tex_true) ** 2)))
-    return dict(iters=iters, res=res, ref_res=ref_res, tex=tex_size, loss_first=float(np.mean(losses[:5])),
+    return dict(iters=iters, res=res, ref_res=ref_res, tex=tex_size, graph=bool(graph), loss_first=float(np.mean(losses[:5])),
                 loss_last=float(np.mean(losses[-5:])), tex_rmse_before=rmse0, tex_rmse_after=rmse1,
                 iters_per_s=round(iters / dt, 1))
 
@@ -102,5 +132,6 @@ if __name__ == "__main__":
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--ref-res", type=int, default=1024)
     ap.add_argument("--tex", type=int, default=512)
+    ap.add_argument("--graph", action="store_true", help="capture one iteration into a hipGraph and replay it")
     a = ap.parse_args()
-    print(json.dumps(fit(a.iters, a.res, a.ref_res, a.tex)))
+    print(json.dumps(fit(a.iters, a.res, a.ref_res, a.tex, graph=a.graph)))
