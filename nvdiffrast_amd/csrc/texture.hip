@@ -33,7 +33,7 @@ struct TexParams {
 __device__ __forceinline__ int level_dim(int d, int level) { int v = d >> level; return v > 1 ? v : 1; }
 
 // texture_kernel.cu:322-366
-__device__ __forceinline__ long long tex_index_nearest(const TexParams& p, float u, float v, int tz)
+__device__ __forceinline__ int tex_index_nearest(const TexParams& p, float u, float v, int tz)
 {
 #pragma clang fp contract(off)
     const int w = p.texW, h = p.texH;
@@ -44,13 +44,13 @@ __device__ __forceinline__ long long tex_index_nearest(const TexParams& p, float
     if (p.boundary == TEX_B_ZERO && (iu < 0 || iu >= w || iv < 0 || iv >= h)) return -1;
     iu = min(max(iu, 0), w - 1);
     iv = min(max(iv, 0), h - 1);
-    return (long long)iu + (long long)w * (iv + (long long)tz * h);
+    return iu + w * (iv + tz * h);
 }
 
 // Bilinear footprint: texel indices of taps x0y0, x1y0, x0y1, x1y1 (-1 = no texel), weights, and each
 // tap's texel column / row inside its slice (cube maps: row = y + w * face).  `corner` marks a cube
 // corner footprint, whose missing texel stands for the average of the other three.
-struct Quad { long long tc[4]; float fu, fv; int tx[4], ty[4]; bool corner; };
+struct Quad { int tc[4]; float fu, fv; int tx[4], ty[4]; bool corner; };
 
 // texture_kernel.cu:368-472.  The one explicit fma is where the reference's compiler contracts.
 __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, float v, int tz, int level)
@@ -81,11 +81,11 @@ __device__ __forceinline__ Quad tex_index_linear(const TexParams& p, float u, fl
     q.tx[0] = iu0; q.tx[1] = iu1; q.tx[2] = iu0; q.tx[3] = iu1;
     q.ty[0] = iv0; q.ty[1] = iv0; q.ty[2] = iv1; q.ty[3] = iv1;
     q.corner = false;
-    const long long base = (long long)tz * w * h;
-    q.tc[0] = base + iu0 + (long long)w * iv0;
-    q.tc[1] = base + iu1 + (long long)w * iv0;
-    q.tc[2] = base + iu0 + (long long)w * iv1;
-    q.tc[3] = base + iu1 + (long long)w * iv1;
+    const int base = tz * w * h;
+    q.tc[0] = base + iu0 + w * iv0;
+    q.tc[1] = base + iu1 + w * iv0;
+    q.tc[2] = base + iu0 + w * iv1;
+    q.tc[3] = base + iu1 + w * iv1;
     if (p.boundary == TEX_B_ZERO) {
         const bool u0o = (iu0 < 0 || iu0 >= w), u1o = (iu1 < 0 || iu1 >= w);
         const bool v0o = (iv0 < 0 || iv0 >= h), v1o = (iv1 < 0 || iv1 >= h);
@@ -189,11 +189,11 @@ __device__ __forceinline__ Quad tex_index_linear_cube(const TexParams& p, float3
     const float u = __fmaf_rn(s, (float)w, -0.5f), v = __fmaf_rn(t, (float)w, -0.5f);
     const int iu0 = __float2int_rd(u), iv0 = __float2int_rd(v);
     q.fu = u - (float)iu0; q.fv = v - (float)iv0;
-    const long long base = 6ll * tz * w * w;
+    const int base = 6 * tz * w * w;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int cx, cy;
-        if (cube_texel(f, iu0 + (k & 1), iv0 + (k >> 1), w, cx, cy)) { q.tx[k] = cx; q.ty[k] = cy; q.tc[k] = base + cx + (long long)w * cy; }
+        if (cube_texel(f, iu0 + (k & 1), iv0 + (k >> 1), w, cx, cy)) { q.tx[k] = cx; q.ty[k] = cy; q.tc[k] = base + cx + w * cy; }
         else q.corner = true;
     }
     return q;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void corner_weights(const Quad& q, float w[4])
 }
 
 // Nearest texel of a cube map (:331-338): no wrap, the face is folded into the slice index.
-__device__ __forceinline__ long long tex_index_nearest_cube(const TexParams& p, float3 v, int tz, int& x, int& y)
+__device__ __forceinline__ int tex_index_nearest_cube(const TexParams& p, float3 v, int tz, int& x, int& y)
 {
 #pragma clang fp contract(off)
     float s, t;
@@ -362,7 +362,7 @@ __device__ __forceinline__ long long tex_index_nearest_cube(const TexParams& p, 
     iu = min(max(iu, 0), w - 1);
     iv = min(max(iv, 0), w - 1);
     x = iu; y = iv + w * f;
-    return (long long)iu + (long long)w * (y + 6ll * tz * w);
+    return iu + w * (y + 6 * tz * w);
 }
 
 __device__ __forceinline__ float lerp1(float a, float b, float c) { return a + c * (b - a); }
@@ -372,7 +372,7 @@ __device__ __forceinline__ float bilerp1(float a, float b, float c, float d, flo
 template <int C_CT> struct TexelVec { float v[C_CT > 0 ? C_CT : 1]; };
 
 template <int C_CT>
-__device__ __forceinline__ void load_texel(float* dst, const float* base, long long tc, int C)
+__device__ __forceinline__ void load_texel(float* dst, const float* base, int tc, int C)
 {
     if (tc < 0) { for (int c = 0; c < (C_CT > 0 ? C_CT : C); c++) dst[c] = 0.f; return; }
     const float* s = base + tc * (C_CT > 0 ? C_CT : C);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
     float* pOut = p.out + pidx * C;
 
     if (FILTER == TEX_NEAREST) {
-        const long long tc = tex_index_nearest(p, uv.x, uv.y, tz);
+        const int tc = tex_index_nearest(p, uv.x, uv.y, tz);
         if (C_CT > 0) {
             float t[CMAX];
             load_texel<C_CT>(t, p.tex[0], tc, C);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
 
     if (FILTER == TEX_NEAREST) {
         int x, y;
-        const long long tc = tex_index_nearest_cube(p, uv3, tz, x, y);
+        const int tc = tex_index_nearest_cube(p, uv3, tz, x, y);
         for (int c = 0; c < C; c++) pOut[c] = tc >= 0 ? p.tex[0][tc * C + c] : 0.f;
         return;
     }
@@ -549,11 +549,11 @@ struct PatchTable {
     }
 };
 
-template <int FILTER, bool BIAS_ONLY, bool CUBE>
+template <int FILTER, bool BIAS_ONLY, bool CUBE, int C_CT>
 __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int groups)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    const int C = p.channels;
+    const int C = C_CT > 0 ? C_CT : p.channels;          // compile-time channel count for the common cases: the loops unroll
     PatchTable tab{(unsigned long long*)s_mem, (int*)((unsigned long long*)s_mem + groups), groups, C};
     uint32_t* s_max = (uint32_t*)(tab.vals + (size_t)groups * 16 * C);
     int px = 0, py = 0, pz = 0; bool inside;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
 
     // One tap's contribution: LDS table when it has a slot, global atomic otherwise.
     const bool noScatter = p.dbg & 512;
-    auto scatter = [&](int slot, int level, long long tc, int c, float v) {
+    auto scatter = [&](int slot, int level, int tc, int c, float v) {
         if (noScatter) return;
         if (slot >= 0) atomicAdd(&tab.vals[(size_t)slot * C + c], fs.to_fixed(v));
         else atomic_add_f32(p.gradTex[level] + tc * C + c, v);
@@ -651,11 +651,11 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
 
         if (FILTER == TEX_NEAREST) {
             int x = 0, y = 0;
-            long long tc;
+            int tc;
             if (CUBE) tc = tex_index_nearest_cube(p, uv3, tz, x, y);
             else {
                 tc = tex_index_nearest(p, uv3.x, uv3.y, tz);
-                if (tc >= 0) { const long long t = tc - (long long)tz * p.texW * p.texH; y = (int)(t / p.texW); x = (int)(t - (long long)y * p.texW); }
+                if (tc >= 0) { const int t = tc - tz * p.texW * p.texH; y = t / p.texW; x = t - y * p.texW; }
             }
             if (tc >= 0) {
                 const int sl = direct ? -1 : tab.find(0, x, y);
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         const int y = (int)((key >> 29) & 0x1FFFFFFFull) * 2 + (tx >> 3);
         const int w = level_dim(p.texW, level), h = level_dim(p.texH, level) * (CUBE ? 6 : 1);
         if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
-        atomic_add_f32(p.gradTex[level] + (((long long)tz * h + y) * w + x) * C + c, fs.to_float(t));
+        atomic_add_f32(p.gradTex[level] + ((tz * h + y) * w + x) * C + c, fs.to_float(t));
     }
 }
 
@@ -865,6 +865,8 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
     }
     NVDR_REQUIRE(tex_n == 1 || tex_n == N, "minibatch size mismatch between inputs tex, uv");
     NVDR_REQUIRE(tex_w <= (1 << 16) && tex_h <= (1 << 16), "texture size too large");
+    // 32-bit element indices, like the reference (texture.h:24: "a texture cannot be larger than 2 GB").
+    NVDR_REQUIRE((long long)tex_n * (cube ? 6 : 1) * tex_h * tex_w * C < (1ll << 31), "texture size too large (more than 2^31 elements)");
     const bool mips = (filter == TEX_LMN || filter == TEX_LML);
     if (mips) {
         NVDR_REQUIRE(uv_da || bias, "mipmapping filter mode requires uv_da and/or mip_level_bias input");
@@ -1029,10 +1031,14 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     const size_t lds = (size_t)groups * (8 + 64 * (size_t)C) + 16;
     {
         ProfileScope ps("tex_grad", stream);
+#define NVDR_TEX_GRAD_C(FILTER, BO, CUBE, CC) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, CUBE, CC>), grid, dim3(256), lds, stream, p, groups)
 #define NVDR_TEX_GRAD(FILTER, BO)                                                                              \
     do {                                                                                                       \
-        if (cube) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, true>), grid, dim3(256), lds, stream, p, groups);  \
-        else      hipLaunchKernelGGL((k_tex_grad<FILTER, BO, false>), grid, dim3(256), lds, stream, p, groups); \
+        if (cube) NVDR_TEX_GRAD_C(FILTER, BO, true, 0);                                                        \
+        else if (!BO && (FILTER == TEX_LINEAR || FILTER == TEX_LML) && C >= 1 && C <= 4) {                     \
+            if (C == 1) NVDR_TEX_GRAD_C(FILTER, false, false, 1); else if (C == 2) NVDR_TEX_GRAD_C(FILTER, false, false, 2); \
+            else if (C == 3) NVDR_TEX_GRAD_C(FILTER, false, false, 3); else NVDR_TEX_GRAD_C(FILTER, false, false, 4);        \
+        } else NVDR_TEX_GRAD_C(FILTER, BO, false, 0);                                                          \
     } while (0)
         switch (filter_mode) {
         case TEX_NEAREST: NVDR_TEX_GRAD(TEX_NEAREST, false); break;
