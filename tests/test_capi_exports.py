@@ -57,6 +57,29 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert rc == 1
 
 
+def test_texture_and_antialias_host_side(lib):
+    import ctypes
+    # mip geometry is pure host code (texture.cpp:62-102)
+    lw = (ctypes.c_int * 17)(); lh = (ctypes.c_int * 17)(); off = (ctypes.c_int64 * 17)(); tot = ctypes.c_int64()
+    L = lib.nvdr_texture_mip_info(2, 8, 32, 3, 0, -1, lw, lh, off, ctypes.byref(tot))
+    assert L == 5 and list(lw[:6]) == [32, 16, 8, 4, 2, 1] and list(lh[:6]) == [8, 4, 2, 1, 1, 1]
+    assert tot.value == 2 * 3 * (16 * 4 + 8 * 2 + 4 + 2 + 1) and off[1] == 0 and off[2] == 2 * 3 * 64
+    assert lib.nvdr_texture_mip_info(1, 12, 8, 1, 0, -1, lw, lh, off, ctypes.byref(tot)) == -1     # 12 -> 6 -> 3
+    assert lib.nvdr_texture_mip_info(1, 8, 8, 1, 0, 2, lw, lh, off, ctypes.byref(tot)) == 2
+    assert lib.nvdr_texture_mip_info(1, 4, 4, 2, 1, -1, lw, lh, off, ctypes.byref(tot)) == 2 and tot.value == 6 * 2 * (4 + 1)
+    # buffer sizing follows the reference (torch_antialias.cpp:43-49,123)
+    assert lib.nvdr_antialias_hash_bytes(10000) == 16384 * 8 * 16
+    assert lib.nvdr_antialias_hash_bytes(1) == 64 * 8 * 16
+    assert lib.nvdr_antialias_work_bytes(2, 16, 8) == (2 * 16 * 8 * 8 + 4) * 4
+    # argument errors come back as codes + messages before anything is launched
+    rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 1, 1, None, None)
+    assert rc == 1 and b"null pointer" in lib.nvdr_last_error()
+    rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 7, 1, None, None)
+    assert rc == 1 and b"filter_mode unsupported" in lib.nvdr_last_error()
+    rc = lib.nvdr_antialias_fwd(None, None, None, None, None, 0, 1, 1, 3, 1, 4, 4, 3, None, None, 0, None)
+    assert rc == 1 and b"null pointer" in lib.nvdr_last_error()
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "nvdiffrast_amd")
     for dp, _, files in os.walk(pkg):
@@ -83,3 +106,28 @@ def test_cpu_tensors_are_rejected_like_the_reference():
         _plugin.interpolate_fwd(torch.zeros(1, 3, 2), torch.zeros(1, 4, 4, 4), tri)
     with pytest.raises(RuntimeError, match="must reside on the same GPU device"):
         _plugin.rasterize_grad(pos, tri, torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 4, 4))
+    with pytest.raises(RuntimeError, match="must reside on the same GPU device"):
+        _plugin.texture_fwd(torch.zeros(1, 4, 4, 3), torch.zeros(1, 2, 2, 2), 1, 1)
+    with pytest.raises(RuntimeError, match="must reside on the same GPU device"):
+        _plugin.antialias_construct_topology_hash(tri)
+    with pytest.raises(RuntimeError, match="filter_mode unsupported"):
+        _plugin.texture_fwd(torch.zeros(1, 4, 4, 3), torch.zeros(1, 2, 2, 2), 9, 1)
+
+
+def test_public_api_surface_matches_the_reference():
+    """Same public names as nvdiffrast/torch/__init__.py + ops.py of the reference (ops.py:18-559)."""
+    import inspect
+    import nvdiffrast_amd.torch as dr
+    expected = {"RasterizeCudaContext", "RasterizeGLContext", "get_log_level", "set_log_level", "rasterize",
+                "DepthPeeler", "interpolate", "texture", "texture_construct_mip", "antialias",
+                "antialias_construct_topology_hash"}
+    assert expected <= set(dir(dr))
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(dr.rasterize) == ["glctx", "pos", "tri", "resolution", "ranges", "grad_db"]
+    assert sig(dr.interpolate) == ["attr", "rast", "tri", "rast_db", "diff_attrs"]
+    assert sig(dr.texture) == ["tex", "uv", "uv_da", "mip_level_bias", "mip", "filter_mode", "boundary_mode", "max_mip_level"]
+    assert sig(dr.antialias) == ["color", "rast", "pos", "tri", "topology_hash", "pos_gradient_boost"]
+    assert sig(dr.texture_construct_mip) == ["tex", "max_mip_level", "cube_mode"]
+    assert inspect.signature(dr.texture).parameters["filter_mode"].default == "auto"
+    assert inspect.signature(dr.texture).parameters["boundary_mode"].default == "wrap"
+    assert inspect.signature(dr.antialias).parameters["pos_gradient_boost"].default == 1.0
