@@ -269,7 +269,9 @@ __device__ int clip_poly_plane(float* out, const float* in, int n_in, float f0, 
 
 // Slow path, TriangleSetup.inl:355-434 + Util.inl:134-160.  Kept out of line so the common
 // path stays small.
-__device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist, uint4* stage)
+// pool_slot < 0: only count the surviving sub-triangles (returned); otherwise emit them, the first into
+// slot0 and the rest into pool slots pool_slot, pool_slot + 1, ... (reserved by the caller).
+__device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist, uint4* stage, int pool_slot)
 {
 #pragma clang fp contract(off)
     float d1[4], d2[4], bary[18], tmp[18];
@@ -301,25 +303,27 @@ __device__ __noinline__ void setup_clipped(const SetupParams& p, int n, int slot
         for (int c = 0; c < 4; c++) cp[c] = cc[c];
     }
 
-    if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return; }
+    if (pool_slot < 0) return ns;
+    if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return 0; }
     emit_record(p, n, slot0, st[0], id, s_hist, stage);
-    if (ns > 1) {
-        int base = atomicAdd(&p.poolCount[n], ns - 1);       // cannot exceed slots - poolBase by construction
-        for (int k = 1; k < ns; k++)
-            emit_record(p, n, p.poolBase + base + k - 1, st[k], id, s_hist, nullptr);
-    }
+    for (int k = 1; k < ns; k++)                             // cannot exceed slots - poolBase by construction
+        emit_record(p, n, p.poolBase + pool_slot + k - 1, st[k], id, s_hist, nullptr);
+    return ns;
 }
 
-__device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage)
+// `clipq` != nullptr: triangles that need the clipper are only queued (their block processes them
+// densely afterwards, see k_setup).  `clipq` == nullptr: run the clipper for triangle i -- counting the
+// sub-triangles when pool_slot < 0, emitting them otherwise.  Returns the sub-triangle count.
+__device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage, int* clipq, int* clipn, int pool_slot = -1)
 {
 #pragma clang fp contract(off)
     int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
-    if (i >= cnt) return;
+    if (i >= cnt) return 0;
     size_t so = (size_t)n * p.slots + i;
     int t = i + (p.instance ? 0 : p.ranges[2 * n]);
-    if ((uint32_t)t >= (uint32_t)p.T) { p.bbox[so] = kEmptyBox; return; }           // :228-233
+    if ((uint32_t)t >= (uint32_t)p.T) { p.bbox[so] = kEmptyBox; return 0; }           // :228-233
     uint32_t i0 = (uint32_t)p.tri[t * 3 + 0], i1 = (uint32_t)p.tri[t * 3 + 1], i2 = (uint32_t)p.tri[t * 3 + 2];
-    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) { p.bbox[so] = kEmptyBox; return; } // :241-248
+    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) { p.bbox[so] = kEmptyBox; return 0; } // :241-248
 
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
     float4 q0 = vb[i0], q1 = vb[i1], q2 = vb[i2];
@@ -337,7 +341,7 @@ __device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, in
             out |= (v[0][3] < +v[0][ax]) & (v[1][3] < +v[1][ax]) & (v[2][3] < +v[2][ax]);
             out |= (v[0][3] < -v[0][ax]) & (v[1][3] < -v[1][ax]) & (v[2][3] < -v[2][ax]);
         }
-        if (out) { p.bbox[so] = kEmptyBox; return; }
+        if (out) { p.bbox[so] = kEmptyBox; return 0; }
     }
 
     bool inside = true;
@@ -349,9 +353,12 @@ __device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, in
         SubTri st;
         if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist, stage);
         else p.bbox[so] = kEmptyBox;
+    } else if (clipq) {
+        clipq[atomicAdd(clipn, 1)] = i;
     } else {
-        setup_clipped(p, n, i, v, t + 1, s_hist, stage);
+        return setup_clipped(p, n, i, v, t + 1, s_hist, stage, pool_slot);
     }
+    return 0;
 }
 
 
@@ -367,8 +374,37 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
     // memory as four partial-line writes each (measured: 4x the bytes).  Slots of culled triangles
     // receive whatever the stage holds; their AABB marks them empty.
     __shared__ uint4 s_rec[256 * 4];
-    setup_one(p, n, blockIdx.x * 256 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4);
+    // The clipper path (triangles crossing a frustum plane: up to seven sub-triangle setups) is an
+    // order of magnitude longer than the common path; run inside the per-triangle pass it would keep
+    // whole waves waiting for their few clipped lanes.  Pass 1 queues those triangles, pass 2 runs
+    // the clipper on the queue with consecutive lanes.
+    __shared__ int s_clipq[256];
+    __shared__ int s_clipn;
+    if (threadIdx.x == 0) s_clipn = 0;
     __syncthreads();
+    const int i0 = blockIdx.x * 256;
+    setup_one(p, n, i0 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4, s_clipq, &s_clipn);
+    __syncthreads();
+    // 2a: count the sub-triangles, reserve the block's pool slots with ONE global atomic (a returning
+    // atomic per clipped triangle on the image's counter serialises: measured 0.5 ms on the stress scene)
+    __shared__ int s_poolNeed, s_poolBase;
+    if (s_clipn > 0) {                                       // uniform: blocks without clipped triangles skip all of it
+        if (threadIdx.x == 0) { s_poolNeed = 0; s_poolBase = 0; }
+        __syncthreads();
+        const bool clip = (int)threadIdx.x < s_clipn;
+        const int ci = clip ? s_clipq[threadIdx.x] : 0;
+        int poolOff = 0;
+        if (clip) {
+            const int ns = setup_one(p, n, ci, s_hist, nullptr, nullptr, nullptr, -1);
+            if (ns > 1) poolOff = atomicAdd(&s_poolNeed, ns - 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_poolNeed > 0) s_poolBase = atomicAdd(&p.poolCount[n], s_poolNeed);
+        __syncthreads();
+        // 2b: emit
+        if (clip) setup_one(p, n, ci, s_hist, s_rec + (ci - i0) * 4, nullptr, nullptr, s_poolBase + poolOff);
+        __syncthreads();
+    }
     {
         const int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
