@@ -59,6 +59,19 @@ __device__ __forceinline__ bool decode_block(int gx, int gy, int N, int& bx, int
     return true;
 }
 
+// ---- streaming accesses ---------------------------------------------------------------
+// Non-temporal 16-byte accesses for tensors that are touched once per kernel and are larger than
+// what can stay cached until their next use: they do not displace the tensors the NEXT kernels
+// re-read (rast, g_rast) from the 256 MB Infinity Cache.
+typedef float nvdr_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_streaming(float4* p, float4 v) {
+    __builtin_nontemporal_store(nvdr_v4f{v.x, v.y, v.z, v.w}, (nvdr_v4f*)p);
+}
+__device__ __forceinline__ float4 load_streaming(const float4* p) {
+    const nvdr_v4f v = __builtin_nontemporal_load((const nvdr_v4f*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // ---- triangle-id <-> f32 codec (reference csrc/common/common.h:186-193) ----------
 // Identity up to 2^24; above that the id is stored as a bit-offset float so that it
 // survives the f32 channel.

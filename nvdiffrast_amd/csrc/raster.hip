@@ -825,7 +825,9 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
         if (write) {
             ((float4*)p.out)[pidx] = o;
-            ((float4*)p.out_db)[pidx] = odb;
+            // rast_db is write-once here and, in most op graphs, read late or never: a non-temporal store
+            // keeps it from displacing `rast` (re-read by the next three kernels) in the Infinity Cache.
+            store_streaming((float4*)p.out_db + pidx, odb);
         }
     }
     if (DBG && p.dbgbuf && lane == 0) {
