@@ -885,79 +885,77 @@ __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const flo
     if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) return false;
     r.tri = triIdx; r.vi0 = vi0; r.vi1 = vi1; r.vi2 = vi2;
 
-    const float4 p0 = vb[vi0], p1 = vb[vi1], p2 = vb[vi2];
+    // Reverse-mode differentiation of the pixel shader (k_fine: barycentrics from the edge functions
+    // of the pixel-relative vertices, rasterize.cu:63-113), written as a tape: forward values first,
+    // then adjoints propagated output -> input.  Semantics of rasterize.cu:119-277: the clamps of the
+    // forward pass are ignored and 1/at is regularised with a signed 1e-6.
+    const float4 P[3] = {vb[vi0], vb[vi1], vb[vi2]};
     const float fx = p.xs * (float)px + p.xo;
     const float fy = p.ys * (float)py + p.yo;
-    const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-    const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-    const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-    const float a0 = p1x * p2y - p1y * p2x;
-    const float a1 = p2x * p0y - p2y * p0x;
-    const float a2 = p0x * p1y - p0y * p1x;
+    float X[3], Y[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { X[k] = P[k].x - fx * P[k].w; Y[k] = P[k].y - fy * P[k].w; }
+    float a[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const int i = (k + 1) % 3, j = (k + 2) % 3; a[k] = X[i] * Y[j] - Y[i] * X[j]; }
+    const float at = a[0] + a[1] + a[2];
+    const float iw = 1.f / (at + copysignf(1e-6f, at));
+    const float b0 = a[0] * iw, b1 = a[1] * iw;
 
-    const float at = a0 + a1 + a2;
-    const float ep = copysignf(1e-6f, at);
-    const float iw = 1.f / (at + ep);
-    const float b0 = a0 * iw, b1 = a1 * iw;
-
-    const float gb0 = dy.x * iw, gb1 = dy.y * iw;
-    const float gbb = gb0 * b0 + gb1 * b1;
-    float gp0x = gbb * (p2y - p1y) - gb1 * p2y;
-    float gp1x = gbb * (p0y - p2y) + gb0 * p2y;
-    float gp2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
-    float gp0y = gbb * (p1x - p2x) + gb1 * p2x;
-    float gp1y = gbb * (p2x - p0x) - gb0 * p2x;
-    float gp2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
-    float gp0w = -fx * gp0x - fy * gp0y;
-    float gp1w = -fx * gp1x - fy * gp1y;
-    float gp2w = -fx * gp2x - fy * gp2y;
-
+    float gb0 = dy.x, gb1 = dy.y;          // adjoints of the barycentrics
+    float giw = 0.f;                       // adjoint of iw from everything except b0, b1
+    float gx[3] = {0.f, 0.f, 0.f}, gyv[3] = {0.f, 0.f, 0.f}, gw[3] = {0.f, 0.f, 0.f};    // adjoints of the raw x, y, w
     if (ENABLE_DB && (((uint32_t)grad_all_ddb) << 1) != 0u) {
-        const float dfxdX = p.xs * iw, dfydY = p.ys * iw;
-        ddb.x *= dfxdX; ddb.y *= dfydY; ddb.z *= dfxdX; ddb.w *= dfydY;
-
-        const float da0dX = p1.y * p2.w - p2.y * p1.w;
-        const float da1dX = p2.y * p0.w - p0.y * p2.w;
-        const float da2dX = p0.y * p1.w - p1.y * p0.w;
-        const float da0dY = p2.x * p1.w - p1.x * p2.w;
-        const float da1dY = p0.x * p2.w - p2.x * p0.w;
-        const float da2dY = p1.x * p0.w - p0.x * p1.w;
-        const float datdX = da0dX + da1dX + da2dX;
-        const float datdY = da0dY + da1dY + da2dY;
-
-        const float x01 = p0.x - p1.x, x12 = p1.x - p2.x, x20 = p2.x - p0.x;
-        const float y01 = p0.y - p1.y, y12 = p1.y - p2.y, y20 = p2.y - p0.y;
-        const float w01 = p0.w - p1.w, w12 = p1.w - p2.w, w20 = p2.w - p0.w;
-
-        const float a0p1 = fy * p2.x - fx * p2.y;
-        const float a0p2 = fx * p1.y - fy * p1.x;
-        const float a1p0 = fx * p2.y - fy * p2.x;
-        const float a1p2 = fy * p0.x - fx * p0.y;
-
-        const float wdudX = 2.f * b0 * datdX - da0dX;
-        const float wdudY = 2.f * b0 * datdY - da0dY;
-        const float wdvdX = 2.f * b1 * datdX - da1dX;
-        const float wdvdY = 2.f * b1 * datdY - da1dY;
-
-        const float c0  = iw * (ddb.x * wdudX + ddb.y * wdudY + ddb.z * wdvdX + ddb.w * wdvdY);
-        const float cx  = c0 * fx - ddb.x * b0 - ddb.z * b1;
-        const float cy  = c0 * fy - ddb.y * b0 - ddb.w * b1;
-        const float cxy = iw * (ddb.x * datdX + ddb.y * datdY);
-        const float czw = iw * (ddb.z * datdX + ddb.w * datdY);
-
-        gp0x += c0 * y12 - cy * w12 + czw * p2y + ddb.w * p2.w;
-        gp1x += c0 * y20 - cy * w20 - cxy * p2y - ddb.y * p2.w;
-        gp2x += c0 * y01 - cy * w01 + cxy * p1y - czw * p0y + ddb.y * p1.w - ddb.w * p0.w;
-        gp0y += cx * w12 - c0 * x12 - czw * p2x - ddb.z * p2.w;
-        gp1y += cx * w20 - c0 * x20 + cxy * p2x + ddb.x * p2.w;
-        gp2y += cx * w01 - c0 * x01 - cxy * p1x + czw * p0x - ddb.x * p1.w + ddb.z * p0.w;
-        gp0w += cy * x12 - cx * y12 - czw * a1p0 + ddb.z * p2.y - ddb.w * p2.x;
-        gp1w += cy * x20 - cx * y20 - cxy * a0p1 - ddb.x * p2.y + ddb.y * p2.x;
-        gp2w += cy * x01 - cx * y01 - cxy * a0p2 - czw * a1p2 + ddb.x * p1.y - ddb.y * p1.x - ddb.z * p0.y + ddb.w * p0.x;
+        // rast_db = (sx*(b0*DtX - D0X), sy*(b0*DtY - D0Y), sx*(b1*DtX - D1X), sy*(b1*DtY - D1Y)) with
+        // sx = xs*iw, sy = ys*iw, D_kX = y_j w_i - y_i w_j, D_kY = x_i w_j - x_j w_i (i = k+1, j = k+2), Dt = sum.
+        float DX[3], DY[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = (k + 1) % 3, j = (k + 2) % 3;
+            DX[k] = P[j].y * P[i].w - P[i].y * P[j].w;
+            DY[k] = P[i].x * P[j].w - P[j].x * P[i].w;
+        }
+        const float DtX = DX[0] + DX[1] + DX[2], DtY = DY[0] + DY[1] + DY[2];
+        const float sx = p.xs * iw, sy = p.ys * iw;
+        // adjoints of T_kX = b_k*DtX - D_kX (k = 0, 1) and of sx, sy
+        const float t0x = ddb.x * sx, t0y = ddb.y * sy, t1x = ddb.z * sx, t1y = ddb.w * sy;
+        giw = p.xs * (ddb.x * (b0 * DtX - DX[0]) + ddb.z * (b1 * DtX - DX[1]))
+            + p.ys * (ddb.y * (b0 * DtY - DY[0]) + ddb.w * (b1 * DtY - DY[1]));
+        gb0 += t0x * DtX + t0y * DtY;
+        gb1 += t1x * DtX + t1y * DtY;
+        const float gDtX = t0x * b0 + t1x * b1, gDtY = t0y * b0 + t1y * b1;
+        const float gDX[3] = {gDtX - t0x, gDtX - t1x, gDtX};
+        const float gDY[3] = {gDtY - t0y, gDtY - t1y, gDtY};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = (k + 1) % 3, j = (k + 2) % 3;
+            // D_kX = y_j w_i - y_i w_j
+            gyv[j] += gDX[k] * P[i].w; gw[i] += gDX[k] * P[j].y;
+            gyv[i] -= gDX[k] * P[j].w; gw[j] -= gDX[k] * P[i].y;
+            // D_kY = x_i w_j - x_j w_i
+            gx[i] += gDY[k] * P[j].w; gw[j] += gDY[k] * P[i].x;
+            gx[j] -= gDY[k] * P[i].w; gw[i] -= gDY[k] * P[j].x;
+        }
     }
-    r.g[0] = gp0x; r.g[1] = gp0y; r.g[2] = gp0w;
-    r.g[3] = gp1x; r.g[4] = gp1y; r.g[5] = gp1w;
-    r.g[6] = gp2x; r.g[7] = gp2y; r.g[8] = gp2w;
+    // b_k = a_k * iw, iw = 1 / at', at = a0 + a1 + a2
+    giw += gb0 * a[0] + gb1 * a[1];
+    const float gat = -giw * iw * iw;
+    const float ga[3] = {gb0 * iw + gat, gb1 * iw + gat, gat};
+    // a_k = X_i Y_j - Y_i X_j
+    float gX[3] = {0.f, 0.f, 0.f}, gY[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = (k + 1) % 3, j = (k + 2) % 3;
+        gX[i] += ga[k] * Y[j]; gY[j] += ga[k] * X[i];
+        gY[i] -= ga[k] * X[j]; gX[j] -= ga[k] * Y[i];
+    }
+    // X_k = x_k - fx w_k, Y_k = y_k - fy w_k
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r.g[k * 3 + 0] = gx[k] + gX[k];
+        r.g[k * 3 + 1] = gyv[k] + gY[k];
+        r.g[k * 3 + 2] = gw[k] - fx * gX[k] - fy * gY[k];
+    }
     return true;
 }
 
