@@ -189,56 +189,60 @@ __global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
         if (tri == tri1) { px += 1 - d; py += d; }
         if (tri < 0 || tri >= p.numTriangles) continue;
 
-        int vi0 = p.tri[tri * 3 + 0], vi1 = p.tri[tri * 3 + 1], vi2 = p.tri[tri * 3 + 2];
-        if (vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices) continue;
+        int vi[3];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { vi[k] = p.tri[tri * 3 + k]; bad |= (vi[k] < 0 || vi[k] >= p.numVertices); }
+        if (bad) continue;
 
-        int op0 = hash_find_vertex(p, vi2, vi1, vi0);
-        int op1 = hash_find_vertex(p, vi0, vi2, vi1);
-        int op2 = hash_find_vertex(p, vi1, vi0, vi2);
-        // A table built for another mesh may name vertices this one does not have.
-        if (op0 >= p.numVertices) op0 = -1;
-        if (op1 >= p.numVertices) op1 = -1;
-        if (op2 >= p.numVertices) op2 = -1;
+        // Triangle corners and, per edge, the vertex across it in the neighbouring triangle (the corner
+        // itself when the edge has no neighbour: always a silhouette), projected to pixel units
+        // relative to the centre of the pixel the edge distance is measured from (:275-319).
         const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)pz * p.numVertices : 0);
-        const float4 p0 = vb[vi0], p1 = vb[vi1], p2 = vb[vi2];
-        const float4 o0 = (op0 < 0) ? p0 : vb[op0];
-        const float4 o1 = (op1 < 0) ? p1 : vb[op1];
-        const float4 o2 = (op2 < 0) ? p2 : vb[op2];
-
-        const float w0 = 1.f / p0.w, w1 = 1.f / p1.w, w2 = 1.f / p2.w;
-        const float ow0 = 1.f / o0.w, ow1 = 1.f / o1.w, ow2 = 1.f / o2.w;
         const float fx = (float)px + .5f - p.xh;
         const float fy = (float)py + .5f - p.yh;
-        float x0 = p0.x * w0 * p.xh - fx, y0 = p0.y * w0 * p.yh - fy;
-        float x1 = p1.x * w1 * p.xh - fx, y1 = p1.y * w1 * p.yh - fy;
-        float x2 = p2.x * w2 * p.xh - fx, y2 = p2.y * w2 * p.yh - fy;
-        const float ox0 = o0.x * ow0 * p.xh - fx, oy0 = o0.y * ow0 * p.yh - fy;
-        const float ox1 = o1.x * ow1 * p.xh - fx, oy1 = o1.y * ow1 * p.yh - fy;
-        const float ox2 = o2.x * ow2 * p.xh - fx, oy2 = o2.y * ow2 * p.yh - fy;
+        float x[3], y[3], ox[3], oy[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = (k + 1) % 3, j = (k + 2) % 3;
+            int op = hash_find_vertex(p, vi[j], vi[i], vi[k]);      // vertex opposite to corner k across edge (i, j)
+            if (op >= p.numVertices) op = -1;                       // a table built for another mesh may name vertices this one lacks
+            const float4 c = vb[vi[k]];
+            const float4 o = (op < 0) ? c : vb[op];
+            const float w = 1.f / c.w, ow = 1.f / o.w;
+            x[k] = c.x * w * p.xh - fx;   y[k] = c.y * w * p.yh - fy;
+            ox[k] = o.x * ow * p.xh - fx; oy[k] = o.y * ow * p.yh - fy;
+        }
 
-        const float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-        const float a0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
-        const float a1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
-        const float a2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
-        if (!(same_sign(a0, bb) || same_sign(a1, bb) || same_sign(a2, bb))) continue;
+        // Orientation of the triangle and of each "wing" (edge + opposite vertex): an edge whose wing
+        // folds to the same side as the triangle is a silhouette (:321-328).
+        const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+        bool sil[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = (k + 1) % 3, j = (k + 2) % 3;
+            const float wing = (x[i] - ox[k]) * (y[j] - oy[k]) - (x[j] - ox[k]) * (y[i] - oy[k]);
+            sil[k] = same_sign(wing, bb);
+        }
+        if (!(sil[0] || sil[1] || sil[2])) continue;
 
-        if (d) { swapf(x0, y0); swapf(x1, y1); swapf(x2, y2); }
-        const float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
-        float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
-
-        float dc = -kF32Max;
+        // Work in a frame where the pixel pair is horizontal (:330-336), then find the edge that
+        // crosses the segment between the two pixel centres nearest to this pixel (:338-359).
+        if (d) { swapf(x[0], y[0]); swapf(x[1], y[1]); swapf(x[2], y[2]); }
         const float ds = (tri == tri0) ? 1.f : -1.f;
-        float d0 = ds * (x1 * dy0 - y1 * dx0);
-        float d1 = ds * (x2 * dy1 - y2 * dx1);
-        float d2 = ds * (x0 * dy2 - y0 * dx2);
-        if (same_sign(y1, y2)) { d0 = -kF32Max; dy0 = 1.f; }
-        if (same_sign(y2, y0)) { d1 = -kF32Max; dy1 = 1.f; }
-        if (same_sign(y0, y1)) { d2 = -kF32Max; dy2 = 1.f; }
-
-        const int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
-        if (di == 0 && same_sign(a0, bb) && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
-        if (di == 1 && same_sign(a1, bb) && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
-        if (di == 2 && same_sign(a2, bb) && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
+        float ex[3], ey[3], dist[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int i = (k + 1) % 3, j = (k + 2) % 3;
+            ex[k] = x[j] - x[i]; ey[k] = y[j] - y[i];
+            dist[k] = ds * (x[i] * ey[k] - y[i] * ex[k]);
+            if (same_sign(y[i], y[j])) { dist[k] = -kF32Max; ey[k] = 1.f; }     // the edge does not cross the row
+        }
+        const int di = max_idx3(dist[0], dist[1], dist[2], ey[0], ey[1], ey[2]);
+        float dc = -kF32Max;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (di == k && sil[k] && fabsf(ey[k]) >= fabsf(ex[k])) dc = dist[k] / ey[k];
         const float eps = .0625f;
 
         if (dc > -eps && dc < 1.f + eps) {

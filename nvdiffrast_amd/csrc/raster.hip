@@ -792,35 +792,37 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) {
                 write = false;                       // reference leaves the pixel untouched (:43-47)
             } else {
-                float4 p0 = vb[vi0], p1 = vb[vi1], p2 = vb[vi2];
-                float fx = p.xs * (float)px + p.xo;
-                float fy = p.ys * (float)py + p.yo;
-                float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-                float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-                float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-                float a0 = p1x * p2y - p1y * p2x;
-                float a1 = p2x * p0y - p2y * p0x;
-                float a2 = p0x * p1y - p0y * p1x;
+                // Perspective-correct barycentrics from the edge functions of the pixel-relative
+                // vertices (rasterize.cu:63-113), in the same cyclic form as the backward tape
+                // (raster_pixel_grad): a_k = X_i Y_j - Y_i X_j, i = k+1, j = k+2.
+                const float4 P[3] = {vb[vi0], vb[vi1], vb[vi2]};
+                const float fx = p.xs * (float)px + p.xo;
+                const float fy = p.ys * (float)py + p.yo;
+                float Xr[3], Yr[3], a[3], DX[3], DY[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { Xr[k] = P[k].x - fx * P[k].w; Yr[k] = P[k].y - fy * P[k].w; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int i = (k + 1) % 3, j = (k + 2) % 3;
+                    a[k] = Xr[i] * Yr[j] - Yr[i] * Xr[j];
+                    DX[k] = P[j].y * P[i].w - P[i].y * P[j].w;          // d a_k / d fx
+                    DY[k] = P[i].x * P[j].w - P[j].x * P[i].w;          // d a_k / d fy
+                }
                 // v_rcp_f32 (1 ulp) instead of IEEE division: three divisions per pixel are a sixth of
                 // this kernel's instruction count, and these outputs carry a 1e-5 tolerance.
-                float iw = __builtin_amdgcn_rcpf(a0 + a1 + a2);
-                float b0 = a0 * iw, b1 = a1 * iw;
-                float z = p0.z * a0 + p1.z * a1 + p2.z * a2;
-                float w = p0.w * a0 + p1.w * a1 + p2.w * a2;
-                float zw = z * __builtin_amdgcn_rcpf(w);
-                b0 = __saturatef(b0); b1 = __saturatef(b1);
-                float bs = __builtin_amdgcn_rcpf(fmaxf(b0 + b1, 1.f));
+                const float iw = __builtin_amdgcn_rcpf(a[0] + a[1] + a[2]);
+                float b0 = __saturatef(a[0] * iw), b1 = __saturatef(a[1] * iw);
+                const float z = P[0].z * a[0] + P[1].z * a[1] + P[2].z * a[2];
+                const float w = P[0].w * a[0] + P[1].w * a[1] + P[2].w * a[2];
+                const float zw = fmaxf(fminf(z * __builtin_amdgcn_rcpf(w), 1.f), -1.f);
+                const float bs = __builtin_amdgcn_rcpf(fmaxf(b0 + b1, 1.f));     // renormalise after the clamp
                 b0 *= bs; b1 *= bs;
-                zw = fmaxf(fminf(zw, 1.f), -1.f);
                 o = make_float4(b0, b1, zw, triidx_to_float(triIdx + 1));
 
-                float dfxdx = p.xs * iw, dfydy = p.ys * iw;
-                float da0dx = p2.y * p1.w - p1.y * p2.w, da0dy = p1.x * p2.w - p2.x * p1.w;
-                float da1dx = p0.y * p2.w - p2.y * p0.w, da1dy = p2.x * p0.w - p0.x * p2.w;
-                float da2dx = p1.y * p0.w - p0.y * p1.w, da2dy = p0.x * p1.w - p1.x * p0.w;
-                float datdx = da0dx + da1dx + da2dx, datdy = da0dy + da1dy + da2dy;
-                odb = make_float4(dfxdx * (b0 * datdx - da0dx), dfydy * (b0 * datdy - da0dy),
-                                  dfxdx * (b1 * datdx - da1dx), dfydy * (b1 * datdy - da1dy));
+                const float sx = p.xs * iw, sy = p.ys * iw;
+                const float DtX = DX[0] + DX[1] + DX[2], DtY = DY[0] + DY[1] + DY[2];
+                odb = make_float4(sx * (b0 * DtX - DX[0]), sy * (b0 * DtY - DY[0]),
+                                  sx * (b1 * DtX - DX[1]), sy * (b1 * DtY - DY[1]));
             }
         }
         if (write) {
