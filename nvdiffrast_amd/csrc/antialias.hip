@@ -302,39 +302,47 @@ __global__ __launch_bounds__(256) void k_aa_grad(const AAParams p)
         }
         if (dd == 0.f) continue;
 
-        const int i1 = (di < 2) ? (di + 1) : 0;
-        const int i2 = (i1 < 2) ? (i1 + 1) : 0;
-        int vi1 = p.tri[3 * tri + i1], vi2 = p.tri[3 * tri + i2];
-        if (vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices) continue;
-        if (p.instance) { vi1 += pz * p.numVertices; vi2 += pz * p.numVertices; }
-
-        float4 p1 = ((const float4*)p.pos)[vi1];
-        float4 p2 = ((const float4*)p.pos)[vi2];
-        float pxh = p.xh, pyh = p.yh;
-        float fx = (float)px + .5f - pxh;
-        float fy = (float)py + .5f - pyh;
-        if (d) { swapf(p1.x, p1.y); swapf(p2.x, p2.y); swapf(pxh, pyh); swapf(fx, fy); }
-
-        const float w1 = 1.f / p1.w, w2 = 1.f / p2.w;
-        const float x1 = p1.x * w1 * pxh - fx, y1 = p1.y * w1 * pyh - fy;
-        const float x2 = p2.x * w2 * pxh - fx, y2 = p2.y * w2 * pyh - fy;
-        const float dx = x2 - x1, dy = y2 - y1;
-        const float db = x1 * dy - y1 * dx;
-        const float ep = copysignf(1e-3f, dy);
-        const float iy = 1.f / (dy + ep);
-        const float dby = db * iy;
-        const float iw1 = -w1 * iy * dd, iw2 = w2 * iy * dd;
-        float gp1x = iw1 * pxh * y2, gp2x = iw2 * pxh * y1;
-        float gp1y = iw1 * pyh * (dby - x2), gp2y = iw2 * pyh * (dby - x1);
-        float gp1w = -(p1.x * gp1x + p1.y * gp1y) * w1;
-        float gp2w = -(p2.x * gp2x + p2.y * gp2y) * w2;
-        if (d) { swapf(gp1x, gp1y); swapf(gp2x, gp2y); }
-        if (fabsf(alpha) >= 0.5f) { gp1x = gp1y = gp1w = 0.f; gp2x = gp2y = gp2w = 0.f; }
-
-        float* q1 = p.gradPos + 4 * (size_t)vi1;
-        float* q2 = p.gradPos + 4 * (size_t)vi2;
-        atomic_add_f32(q1 + 0, gp1x); atomic_add_f32(q1 + 1, gp1y); atomic_add_f32(q1 + 3, gp1w);
-        atomic_add_f32(q2 + 0, gp2x); atomic_add_f32(q2 + 1, gp2y); atomic_add_f32(q2 + 3, gp2w);
+        // The blend weight is alpha = +-(1/2 - c) with c = x1 - y1 (x2 - x1) / (y2 - y1): the crossing of
+        // the silhouette edge (v1, v2) with the row through the pixel centre, in the frame where the
+        // pixel pair is horizontal (:338-365).  dL/dc = -dd; the adjoint runs from c back through the
+        // screen-space edge ends to the clip-space vertices (:508-546).  1 / (y2 - y1) is regularised by
+        // a signed 1e-3 pixel; saturated blends (|alpha| >= 1/2) carry no position gradient.
+        const int e1 = (di + 1) % 3, e2 = (di + 2) % 3;
+        int ve[2] = {p.tri[3 * tri + e1], p.tri[3 * tri + e2]};
+        if (ve[0] < 0 || ve[0] >= p.numVertices || ve[1] < 0 || ve[1] >= p.numVertices) continue;
+        const size_t vbase = p.instance ? (size_t)pz * p.numVertices : 0;
+        // axis a = direction of the pixel pair (0: x, 1: y), b = the other one
+        const float half_a = d ? p.yh : p.xh, half_b = d ? p.xh : p.yh;
+        const float fa = (float)(d ? py : px) + .5f - half_a;
+        const float fb = (float)(d ? px : py) + .5f - half_b;
+        float ca[2], cb[2], rw[2], sa[2], sb[2];               // clip-space coords, 1/w, screen-space coords of the two ends
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float4 v = ((const float4*)p.pos)[vbase + ve[k]];
+            ca[k] = d ? v.y : v.x; cb[k] = d ? v.x : v.y;
+            rw[k] = 1.f / v.w;
+            sa[k] = ca[k] * rw[k] * half_a - fa;
+            sb[k] = cb[k] * rw[k] * half_b - fb;
+        }
+        const float da = sa[1] - sa[0], db = sb[1] - sb[0];
+        const float cross = sa[0] * db - sb[0] * da;
+        const float ib = 1.f / (db + copysignf(1e-3f, db));
+        const float c = cross * ib;
+        // adjoints of the screen-space ends: d c / d sa0 = sb1 / db, d c / d sa1 = -sb0 / db,
+        //                                    d c / d sb0 = (c - sa1) / db, d c / d sb1 = -(c - sa0) / db
+        const float gc = (fabsf(alpha) >= 0.5f) ? 0.f : -dd;
+        const float gsa[2] = {gc * ib * sb[1], -gc * ib * sb[0]};
+        const float gsb[2] = {gc * ib * (c - sa[1]), -gc * ib * (c - sa[0])};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            // s = clip * (1/w) * half - f
+            const float ga = gsa[k] * rw[k] * half_a, gb = gsb[k] * rw[k] * half_b;
+            const float gw = -(ca[k] * ga + cb[k] * gb) * rw[k];
+            float* q = p.gradPos + 4 * (vbase + ve[k]);
+            atomic_add_f32(q + 0, d ? gb : ga);
+            atomic_add_f32(q + 1, d ? ga : gb);
+            atomic_add_f32(q + 3, gw);
+        }
     }
 }
 
