@@ -87,33 +87,44 @@ struct SubTri {
     uint32_t zx, zy, zb;
 };
 
-// Util.inl:184-210 (setupPleq).
+// U32 fixed-point depth plane depth(X, Y) = zb + zx * X + zy * Y (wrapping arithmetic), bit-compatible
+// with the reference's plane equation (Util.inl:184-210) because the visibility test compares these
+// integers.  The scheme, in its own words:
+//   * the three vertex depths (floats in [kDepthMin, kDepthMax]) are truncated to integers after dropping
+//     `drop` low bits, drop = clamp(exponent(max depth) - 22, 0, 8), so that depth differences fit 24+ bits;
+//   * 1/area arrives as a float and is taken apart into a 24-bit mantissa and a right shift, which turns the
+//     division by the area into a 64-bit multiply and an arithmetic shift;
+//   * the plane gradients are (dz x edge) * mantissa >> shift, rescaled from sub-pixel to pixel units;
+//   * the constant is evaluated around an integer pixel near the middle of the triangle (cx, cy), so that
+//     the products that get truncated stay small, and is then moved to the origin with exact U32 wraps.
 __device__ void setup_depth_plane(const float zv[3], int v0x, int v0y, int d1x, int d1y, int d2x, int d2y,
                                   float area_rcp, uint32_t& zx, uint32_t& zy, uint32_t& zb)
 {
-    float mx = fmaxf(fmaxf(zv[0], zv[1]), zv[2]);
-    int sh = min(max((__float_as_int(mx) >> 23) - (127 + 22), 0), 8);
-    int t0 = (int)(cvt_rzi_u32(zv[0]) >> sh);
-    int t1 = (int)(cvt_rzi_u32(zv[1]) >> sh) - t0;
-    int t2 = (int)(cvt_rzi_u32(zv[2]) >> sh) - t0;
+    const float zmax = fmaxf(fmaxf(zv[0], zv[1]), zv[2]);
+    const int drop = min(max(((__float_as_int(zmax) >> 23) - 127) - 22, 0), 8);
+    const int z0  = (int)(cvt_rzi_u32(zv[0]) >> drop);
+    const int dz1 = (int)(cvt_rzi_u32(zv[1]) >> drop) - z0;
+    const int dz2 = (int)(cvt_rzi_u32(zv[2]) >> drop) - z0;
 
-    uint32_t rcp_mant = ((uint32_t)__float_as_int(area_rcp) & 0x007FFFFFu) | 0x00800000u;
-    int rcp_shift = (23 + 127) - (__float_as_int(area_rcp) >> 23);
+    const int rbits = __float_as_int(area_rcp);
+    const long long mant = (long long)(((uint32_t)rbits & 0x007FFFFFu) | 0x00800000u);
+    const int shift = (127 + 23) - (rbits >> 23);            // area_rcp = mant * 2^-shift
 
-    long long xc = ((long long)t1 * d2y - (long long)t2 * d1y) * (long long)rcp_mant;
-    long long yc = ((long long)t2 * d1x - (long long)t1 * d2x) * (long long)rcp_mant;
-    uint32_t px = (uint32_t)(xc >> (rcp_shift - (sh + kSpLog2)));
-    uint32_t py = (uint32_t)(yc >> (rcp_shift - (sh + kSpLog2)));
+    const long long gx = ((long long)dz1 * d2y - (long long)dz2 * d1y) * mant;      // dz/dx * area * mant
+    const long long gy = ((long long)dz2 * d1x - (long long)dz1 * d2x) * mant;
+    const int toPixels = shift - (drop + kSpLog2);
+    zx = (uint32_t)(gx >> toPixels);
+    zy = (uint32_t)(gy >> toPixels);
 
-    int cx = (v0x * 2 + min3i(d1x, d2x, 0) + max3i(d1x, d2x, 0)) >> (kSpLog2 + 1);
-    int cy = (v0y * 2 + min3i(d1y, d2y, 0) + max3i(d1y, d2y, 0)) >> (kSpLog2 + 1);
-    int vcx = v0x - cx * (1 << kSpLog2);
-    int vcy = v0y - cy * (1 << kSpLog2);
+    // reference pixel: centre of the triangle's bounding box, in pixels
+    const int cx = (2 * v0x + min3i(d1x, d2x, 0) + max3i(d1x, d2x, 0)) >> (kSpLog2 + 1);
+    const int cy = (2 * v0y + min3i(d1y, d2y, 0) + max3i(d1y, d2y, 0)) >> (kSpLog2 + 1);
+    const int offx = v0x - (cx << kSpLog2), offy = v0y - (cy << kSpLog2);           // vertex 0 relative to it, sub-pixels
 
-    uint32_t pz = (uint32_t)t0 << sh;
-    pz -= (uint32_t)(((xc >> 13) * vcx + (yc >> 13) * vcy) >> (rcp_shift - (sh + 13)));
-    pz -= px * (uint32_t)cx + py * (uint32_t)cy;
-    zx = px; zy = py; zb = pz;
+    uint32_t c = (uint32_t)z0 << drop;                                              // depth at vertex 0
+    c -= (uint32_t)((((gx >> 13) * offx) + ((gy >> 13) * offy)) >> (shift - (drop + 13)));   // -> depth at (cx, cy)
+    c -= zx * (uint32_t)cx + zy * (uint32_t)cy;                                     // -> depth at the origin
+    zb = c;
 }
 
 // TriangleSetup.inl:11-24, 42-116, 120-177.  Explicit fmaf = the sites nvcc contracts.
