@@ -118,7 +118,7 @@ template <int A_CT, bool ENABLE_DA>
 __global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p, int slots, int gx, int gy)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    constexpr bool kRegs = (A_CT == 4);                     // upstream gradient stays in registers between the phases
+    constexpr bool kRegs = (A_CT == 4 || A_CT == 2);        // upstream gradient stays in registers between the phases
     const int A = A_CT > 0 ? A_CT : p.numAttr;
     unsigned long long* s_vals = (unsigned long long*)s_mem;
     uint32_t* s_keys = (uint32_t*)(s_mem + (size_t)slots * A * 8);
@@ -169,13 +169,20 @@ __global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p
         const float bmax = fmaxf(fmaxf(fabsf(rr.x), fabsf(rr.y)), fabsf(1.f - rr.x - rr.y));
 
         float gb0 = 0.f, gb1 = 0.f, ymax = 0.f;
-        if (kRegs) {
+        if (A_CT == 4) {
             const float4 y = *(const float4*)pdy;
             const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
             gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
             gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
             ymax = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y), y.z), y.w);
             yreg[r] = y;
+        } else if (A_CT == 2) {                             // the usual texture-coordinate case
+            const float2 y = *(const float2*)pdy;
+            const float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
+            gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y);
+            gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y);
+            ymax = max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y);
+            yreg[r] = make_float4(y.x, y.y, 0.f, 0.f);
         } else {
             for (int i = 0; i < A; i++) {
                 const float y = pdy[i];
@@ -371,14 +378,17 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
     const size_t lds = (size_t)slots * (8 * A + 4) + 16;
     NVDR_REQUIRE(lds <= 64 * 1024, "interpolate_grad: too many attributes (%d) for the LDS accumulator", A);
     const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);
+    const bool vec2 = (A == 2) && !((uintptr_t)attr & 7) && !((uintptr_t)dy & 7);
     {
         ProfileScope ps(enable_da ? "interp_grad_da" : "interp_grad", stream);
         if (enable_da) {
-            if (vec4) hipLaunchKernelGGL((k_interp_grad<4, true>), grid, block, lds, stream, p, slots, gx, gy);
-            else      hipLaunchKernelGGL((k_interp_grad<0, true>), grid, block, lds, stream, p, slots, gx, gy);
+            if (vec4)      hipLaunchKernelGGL((k_interp_grad<4, true>), grid, block, lds, stream, p, slots, gx, gy);
+            else if (vec2) hipLaunchKernelGGL((k_interp_grad<2, true>), grid, block, lds, stream, p, slots, gx, gy);
+            else           hipLaunchKernelGGL((k_interp_grad<0, true>), grid, block, lds, stream, p, slots, gx, gy);
         } else {
-            if (vec4) hipLaunchKernelGGL((k_interp_grad<4, false>), grid, block, lds, stream, p, slots, gx, gy);
-            else      hipLaunchKernelGGL((k_interp_grad<0, false>), grid, block, lds, stream, p, slots, gx, gy);
+            if (vec4)      hipLaunchKernelGGL((k_interp_grad<4, false>), grid, block, lds, stream, p, slots, gx, gy);
+            else if (vec2) hipLaunchKernelGGL((k_interp_grad<2, false>), grid, block, lds, stream, p, slots, gx, gy);
+            else           hipLaunchKernelGGL((k_interp_grad<0, false>), grid, block, lds, stream, p, slots, gx, gy);
         }
     }
     NVDR_LAUNCH_CHECK();
