@@ -72,3 +72,12 @@ def test_cube_geometry_is_recovered_through_silhouette_gradients(dr):
     assert r["pos_err_before"] > 0.15
     assert r["pos_err_after"] < 5e-3 and r["col_err_after"] < 5e-3, r
     assert r["loss_last"] < 1e-3 * r["loss_first"], r
+
+
+def test_cube_map_is_learned_from_reflections(dr):
+    """Every texel of all six faces -- edge and corner texels included -- must receive consistent
+    gradients for the environment map to be recovered (cf. samples/torch/envphong.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "samples"))
+    r = _load("fit_envmap_synth").fit(iters=200, res=96, env_size=8, seed=3)
+    assert r["env_rmse_before"] > 0.2 and r["env_rmse_after"] < 2e-3, r
