@@ -443,7 +443,10 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
 // one per XCD (block b of k_fine runs on XCD b % 8, so an image's bins share one L2); inside
 // its chunk each XCD visits the bins with the most triangles first, which keeps the long
 // bins off the tail of the launch.  Counting sort by log2 bucket, one block per chunk.
-__global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount, int* __restrict__ order, int totalBins)
+// Each item is written as {work, triangle count, first scanned slot, scanned length} so that k_fine starts
+// from ONE load instead of a chain of dependent ones (order -> count / slot range -> AABBs).
+__global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount, const int* __restrict__ binHi, const int* __restrict__ binLoInv,
+                                                int4* __restrict__ order, int totalBins)
 {
     __shared__ int s_bucket[32];
     const int perXcd = (totalBins + 7) >> 3;
@@ -465,7 +468,10 @@ __global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount
         int c = binCount[i];
         int bk = c > 0 ? 32 - __clz(c) : 0;
         int pos = atomicAdd(&s_bucket[31 - bk], 1);
-        order[lo + pos] = i;
+        const int hiSlot = binHi[i];
+        const int scanLo = hiSlot ? ((0x7FFFFFFF - binLoInv[i]) & ~3) : 0;
+        const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
+        order[lo + pos] = make_int4(i, c, scanLo, dlen);
     }
 }
 
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount
 
 struct FineParams {
     const uint4* rec; const uint32_t* bbox; const int* poolCount; const int* ranges;
-    const int* binCount; const int* order; const int* binHi; const int* binLoInv;
+    const int4* order;
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
@@ -583,13 +589,14 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int perXcd = (p.totalBins + 7) >> 3;
     const int item = (int)(blockIdx.x & 7) * perXcd + (int)(blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= perXcd || item >= p.totalBins) return;
-    const int work = p.order[item];
+    const int4 it4 = p.order[item];
+    const int work = it4.x;
     const int binsPerImage = p.binsX * p.binsY;
     const int n   = work / binsPerImage;
     const int bin = work - n * binsPerImage;
     const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
     const int btx0 = binX * kBinTiles, bty0 = binY * kBinTiles;
-    const int binTris = p.binCount[work];       // triangles whose AABB touches this bin
+    const int binTris = it4.y;                  // triangles whose AABB touches this bin
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -612,9 +619,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         // recorded the smallest and largest slot that touches the bin; meshes are spatially coherent
         // in index order, so this is a small part of the image's triangles), [dlen, dlen + pool) =
         // the clipper's pool slots.  Four consecutive slots per lane per step.
-        const int hiSlot = p.binHi[work];
-        const int scanLo = hiSlot ? ((0x7FFFFFFF - p.binLoInv[work]) & ~3) : 0;
-        const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
+        const int scanLo = it4.z, dlen = it4.w;
         const int total = dlen + pool;
         const uint32_t* gbox = p.bbox + (size_t)n * p.slots;
         const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
@@ -1090,7 +1095,7 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
     L.binHi = L.binCount + (size_t)N * L.maxBins * 4;
     L.binLoInv = L.binHi + (size_t)N * L.maxBins * 4;
     L.order = align_up(L.binLoInv + (size_t)N * L.maxBins * 4, 256);
-    L.total = align_up(L.order + (size_t)N * L.maxBins * 4, 256);
+    L.total = align_up(L.order + (size_t)N * L.maxBins * 16, 256);
     return L;
 }
 
@@ -1130,7 +1135,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
     int* binCount = (int*)(sb + L.binCount);
     int* binHi = (int*)(sb + L.binHi);
     int* binLoInv = (int*)(sb + L.binLoInv);
-    int* order = (int*)(sb + L.order);
+    int4* order = (int4*)(sb + L.order);
 
     const int Hp = (H + 7) & ~7, Wp = (W + 7) & ~7;
     // Viewport tiling for images beyond 2048 px (torch_rasterize.cpp:99-124).
@@ -1169,7 +1174,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         NVDR_LAUNCH_CHECK();
         {
             ProfileScope ps("raster_order", stream);
-            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, order, totalBins);
+            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, order, totalBins);
         }
         NVDR_LAUNCH_CHECK();
 
@@ -1178,7 +1183,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.instance = sp.instance; fp.N = N; fp.V = V; fp.T = T; fp.maxTri = max_tri; fp.poolBase = L.poolBase; fp.slots = L.slots;
         fp.W = W; fp.H = H; fp.Wp = Wp; fp.Hp = Hp; fp.vp = vp;
         fp.binsX = binsX; fp.binsY = binsY; fp.totalBins = totalBins;
-        fp.binCount = binCount; fp.order = order; fp.binHi = binHi; fp.binLoInv = binLoInv;
+        fp.order = order;
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
