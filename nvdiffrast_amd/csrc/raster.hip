@@ -373,13 +373,15 @@ __device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int
 }
 
 
-__global__ __launch_bounds__(256) void k_setup(const SetupParams p)
+__global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p, int blocksPerImage)
 {
+    // image-major work list cut into one contiguous chunk per XCD (an image's vertices are fetched into one L2)
+    int bxi, byi, n;
+    if (!decode_block(blocksPerImage, 1, p.N, bxi, byi, n)) return;
     __shared__ int s_hist[3 * kMaxBins];              // per bin: count, max slot + 1, INT_MAX - min slot
     const int nb = p.binsX * p.binsY;
     for (int b = threadIdx.x; b < nb; b += 256) { s_hist[b] = 0; s_hist[kMaxBins + b] = 0; s_hist[2 * kMaxBins + b] = 0; }
     __syncthreads();
-    const int n = blockIdx.y;
     // Records are staged in LDS (one 64-byte record per thread) and written out as contiguous 1 KiB
     // rows: the L2 is write-through, so four 16-byte stores at a 64-byte stride per lane would reach
     // memory as four partial-line writes each (measured: 4x the bytes).  Slots of culled triangles
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
     __shared__ int s_clipn;
     if (threadIdx.x == 0) s_clipn = 0;
     __syncthreads();
-    const int i0 = blockIdx.x * 256;
+    const int i0 = bxi * 256;
     setup_one(p, n, i0 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4, s_clipq, &s_clipn);
     __syncthreads();
     // 2a: count the sub-triangles, reserve the block's pool slots with ONE global atomic (a returning
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void k_setup(const SetupParams p)
     {
         const int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const int slot0 = blockIdx.x * 256 + wave * 64;
+        const int slot0 = bxi * 256 + wave * 64;
         uint4* dst = p.rec + ((size_t)n * p.slots + slot0) * 4;
         const uint4* src = s_rec + wave * 64 * 4;
 #pragma unroll
@@ -1169,7 +1171,8 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4 + 3 * (size_t)N * L.maxBins * 4, stream));
         {
             ProfileScope ps("raster_setup", stream);
-            hipLaunchKernelGGL(k_setup, dim3((max_tri + 255) / 256, N, 1), dim3(256), 0, stream, sp);
+            const int bpi = (max_tri + 255) / 256;
+            hipLaunchKernelGGL(k_setup, dim3((unsigned)((((long long)bpi * N + 7) / 8) * 8)), dim3(256), 0, stream, sp, bpi);
         }
         NVDR_LAUNCH_CHECK();
         {
