@@ -112,10 +112,10 @@ constexpr int kIpBlockH = 32;
 constexpr int kIpThreads = 512;
 constexpr int kIpRowsPerWave = 4;
 
-struct IpPixel { int tri, vi0, vi1, vi2; float b0, b1; };
+struct IpPixel { int tri; float b0, b1; };
 
 template <int A_CT, bool ENABLE_DA>
-__global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p, int slots, int gx, int gy)
+__global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k_interp_grad(const InterpParams p, int slots, int gx, int gy)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     constexpr bool kRegs = (A_CT == 4 || A_CT == 2);        // upstream gradient stays in registers between the phases
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p
         if (vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices)
             continue;                                       // corrupt indices: leave untouched (:163-167)
         ok[r] = true;
-        q[r].tri = triIdx; q[r].vi0 = vi0; q[r].vi1 = vi1; q[r].vi2 = vi2; q[r].b0 = rr.x; q[r].b1 = rr.y;
+        q[r].tri = triIdx; q[r].b0 = rr.x; q[r].b1 = rr.y;
         const float* a0 = attr + (size_t)vi0 * A;
         const float* a1 = attr + (size_t)vi1 * A;
         const float* a2 = attr + (size_t)vi2 * A;
@@ -221,13 +221,22 @@ __global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p
     const FixedScale fs(direct ? 0x3F800000u : maxBits);
 
     // ---- phase B -----------------------------------------------------------------------
+    // The vertex indices are fetched again here (L1/L2 hits) instead of being carried in twelve
+    // registers across phase A's peak: that is what lets the kernel run at 8 waves per SIMD.
+    int vi[kIpRowsPerWave][3];
+#pragma unroll
+    for (int r = 0; r < kIpRowsPerWave; r++) {
+        const int t = ok[r] ? q[r].tri : 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) vi[r][k] = p.tri[t * 3 + k];
+    }
 #pragma unroll
     for (int r = 0; r < kIpRowsPerWave; r++) {
         if (__ballot(ok[r]) == 0) continue;
         const RunScan rs(q[r].tri, ok[r]);
         const bool emit = direct ? ok[r] : rs.tail;
         int s0 = -1, s1 = -1, s2 = -1;
-        if (emit && !direct) { s0 = tab.find(q[r].vi0); s1 = tab.find(q[r].vi1); s2 = tab.find(q[r].vi2); }
+        if (emit && !direct) { s0 = tab.find(vi[r][0]); s1 = tab.find(vi[r][1]); s2 = tab.find(vi[r][2]); }
         auto put = [&](int slot, int vi, int i, float v) {
             if (slot >= 0) tab.add(slot, i, fs.to_fixed(v));
             else atomic_add_f32(gattr + (size_t)vi * A + i, v);
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p
             else       y = ok[r] ? pdy[i] : 0.f;
             float v0 = b0 * y, v1 = b1 * y, v2 = b2 * y;
             if (!direct) rs.scan3(v0, v1, v2);
-            if (emit) { put(s0, q[r].vi0, i, v0); put(s1, q[r].vi1, i, v1); put(s2, q[r].vi2, i, v2); }
+            if (emit) { put(s0, vi[r][0], i, v0); put(s1, vi[r][1], i, v1); put(s2, vi[r][2], i, v2); }
         }
         if (ENABLE_DA) {
             float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(kIpThreads) void k_interp_grad(const InterpParams p
                 float dv = d.x * db.z + d.y * db.w;
                 float dw = -du - dv;
                 if (!direct) rs.scan3(du, dv, dw);
-                if (emit) { put(s0, q[r].vi0, j, du); put(s1, q[r].vi1, j, dv); put(s2, q[r].vi2, j, dw); }
+                if (emit) { put(s0, vi[r][0], j, du); put(s1, vi[r][1], j, dv); put(s2, vi[r][2], j, dw); }
             }
         }
     }

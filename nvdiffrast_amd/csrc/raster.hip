@@ -890,18 +890,18 @@ __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const flo
 {
     if (px >= p.W) return false;
     const size_t pidx = ((size_t)pz * p.H + py) * p.W + px;
-    const float4 o = ((const float4*)p.out)[pidx];
-    const float4 d = ((const float4*)p.dy)[pidx];
-    const float2 dy = make_float2(d.x, d.y);
+    const int triIdx = float_to_triidx(p.out[pidx * 4 + 3]) - 1;
+    if (triIdx < 0 || triIdx >= p.T) return false;
+    // Upstream gradients are fetched for covered pixels only (background rows of dy never leave HBM);
+    // these loads travel together with the index loads.
+    const float2 dy = ((const float2*)p.dy)[pidx * 2];
     float4 ddb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ENABLE_DB) ddb = ((const float4*)p.ddb)[pidx];
-    const int triIdx = float_to_triidx(o.w) - 1;
-    if (triIdx < 0 || triIdx >= p.T) return false;
+    const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
     const int grad_all_dy = __float_as_int(dy.x) | __float_as_int(dy.y);
     int grad_all_ddb = 0;
     if (ENABLE_DB) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
     if ((((uint32_t)(grad_all_dy | grad_all_ddb)) << 1) == 0u) return false;          // all +-0 (:143-148)
-    const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
     if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) return false;
     r.tri = triIdx; r.vi0 = vi0; r.vi1 = vi1; r.vi2 = vi2;
 
