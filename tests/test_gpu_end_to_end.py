@@ -81,3 +81,13 @@ def test_cube_map_is_learned_from_reflections(dr):
     sys.path.insert(0, os.path.join(ROOT, "samples"))
     r = _load("fit_envmap_synth").fit(iters=200, res=96, env_size=8, seed=3)
     assert r["env_rmse_before"] > 0.2 and r["env_rmse_after"] < 2e-3, r
+
+
+def test_pose_is_recovered_from_a_single_image(dr):
+    """Batched candidate search + gradient descent on the rotation of a face-coloured cube
+    (cf. samples/torch/pose.py).  interpolate runs with its own index buffer (per-face colours) while
+    rasterize / antialias use the position topology; the pose gradient exists only through antialias."""
+    r = _load("fit_pose_synth").fit(res=64, search=14, candidates=32, descent=300, seed=1)       # short search: descent has work left
+    assert r["err_deg_initial"] > 20, r
+    assert r["err_deg_after_search"] < 25, r
+    assert r["err_deg_final"] < 0.2 and r["err_deg_final"] <= r["err_deg_after_search"], r
