@@ -49,7 +49,12 @@ int  nvdr_profile_read(const char** names, double* total_ms, int* launches, int 
  * (torch_bindings.cpp:54-56; csrc/torch/torch_rasterize.cpp:43-166, 171-263) and the
  * CudaRaster runtime behind them (csrc/common/cudaraster/). */
 
-/* Scratch for one forward call.  max_tri = T (instanced) or max(ranges[:,1]) (range mode). */
+/* Scratch for one forward call.  max_tri = T (instanced) or max(ranges[:,1]) (range mode).
+ * The buffer starts with triangle records and ends with a small control block (counters).  Every
+ * successful nvdr_rasterize_fwd leaves the control block zeroed, which is the state the next call
+ * needs: a caller that passes the SAME buffer with the SAME (N, max_tri, H, W) as its previous
+ * successful call, and has not written to it in between, may say so with scratch_clean = 1 and saves
+ * a memset launch per call.  scratch_clean = 0 is always safe (the library clears the block itself). */
 size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W);
 
 /* instance_mode != 0: pos [N,V,4]; else pos [V,4] and ranges [N,2] (device copy of the
@@ -60,7 +65,7 @@ size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W);
 int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
                        int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                        const uint32_t* peel_depth, uint32_t* depth_out,
-                       void* scratch, size_t scratch_bytes,
+                       void* scratch, size_t scratch_bytes, int scratch_clean,
                        float* out, float* out_db, nvdrStream_t stream);
 
 /* grad_pos (shape of pos) must be zero-filled by the caller (reference: zeros_like,

@@ -17,6 +17,8 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
+ABI_VERSION = 2            # include/nvdr_hip.h; 2: nvdr_rasterize_fwd takes scratch_clean
+
 SIGNATURES = {
     "nvdr_last_error": (ctypes.c_char_p, []),
     "nvdr_abi_version": (c_int, []),
@@ -25,7 +27,7 @@ SIGNATURES = {
     "nvdr_profile_read": (c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), c_int]),
     "nvdr_rasterize_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "nvdr_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
     "nvdr_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nvdr_interpolate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -79,6 +81,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.nvdr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"nvdiffrast_amd: {path} has ABI version {lib.nvdr_abi_version()}, this package needs "
+                           f"{ABI_VERSION}; rebuild it with `python -m nvdiffrast_amd._build`.")
     _lib = lib
     return lib
 

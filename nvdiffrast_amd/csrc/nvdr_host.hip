@@ -58,7 +58,7 @@ void profile_end(hipStream_t s) {
 extern "C" {
 
 const char* nvdr_last_error(void) { return nvdr::g_err; }
-int nvdr_abi_version(void) { return 1; }
+int nvdr_abi_version(void) { return 2; }
 
 void nvdr_profile_enable(int on) { nvdr::g_prof = on != 0; }
 void nvdr_debug_buffer(void* p) { nvdr::g_dbgbuf = (unsigned long long*)p; }

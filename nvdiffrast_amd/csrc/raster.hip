@@ -447,7 +447,10 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p, int block
 // bins off the tail of the launch.  Counting sort by log2 bucket, one block per chunk.
 // Each item is written as {work, triangle count, first scanned slot, scanned length} so that k_fine starts
 // from ONE load instead of a chain of dependent ones (order -> count / slot range -> AABBs).
-__global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount, const int* __restrict__ binHi, const int* __restrict__ binLoInv,
+// The kernel is the last reader of k_setup's counters and zeroes them on the way out: the control
+// block is left as the next rasterize call needs it (no memset launch in front of every call).
+__global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int* __restrict__ binHi, int* __restrict__ binLoInv,
+                                                int* __restrict__ poolCount, int* __restrict__ poolFinal, int N,
                                                 int4* __restrict__ order, int totalBins)
 {
     __shared__ int s_bucket[32];
@@ -474,7 +477,10 @@ __global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount
         const int scanLo = hiSlot ? ((0x7FFFFFFF - binLoInv[i]) & ~3) : 0;
         const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
         order[lo + pos] = make_int4(i, c, scanLo, dlen);
+        binCount[i] = 0; binHi[i] = 0; binLoInv[i] = 0;   // this thread was the bin's only reader in this pass
     }
+    if (blockIdx.x == 0)
+        for (int n = threadIdx.x; n < N; n += 1024) { poolFinal[n] = poolCount[n]; poolCount[n] = 0; }
 }
 
 // ---------------------------------------------------------------------------------
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(1024) void k_order(const int* __restrict__ binCount
 // ---------------------------------------------------------------------------------
 
 struct FineParams {
-    const uint4* rec; const uint32_t* bbox; const int* poolCount; const int* ranges;
+    const uint4* rec; const uint32_t* bbox; const int* poolFinal; const int* ranges;
     const int4* order;
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 
     if (binTris > 0) {
         const int direct = p.instance ? p.T : p.ranges[2 * n + 1];
-        const int pool   = min(p.poolCount[n], p.slots - p.poolBase);
+        const int pool   = min(p.poolFinal[n], p.slots - p.poolBase);
         // Index space scanned by the filter: [0, dlen) = the bin's range of direct slots (k_setup
         // recorded the smallest and largest slot that touches the bin; meshes are spatially coherent
         // in index order, so this is a small part of the image's triangles), [dlen, dlen + pool) =
@@ -1076,7 +1082,7 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 // Host side
 // ---------------------------------------------------------------------------------
 
-struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, order, total; int slots, poolBase, maxBins; };
+struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, order, total; int slots, poolBase, maxBins; };
 
 static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
 {
@@ -1092,11 +1098,14 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
     L.rec   = 0;
     L.bbox  = align_up(L.rec + (size_t)N * L.slots * 64, 256);
     L.pool  = align_up(L.bbox + (size_t)N * L.slots * 4, 256);
-    // pool counters and per-bin counts are adjacent: one memset clears both
+    // Control block [pool, ctlEnd): pool cursors and per-bin counts / slot ranges.  It must be zero when
+    // k_setup starts; k_order, its last reader, leaves it zero again.
     L.binCount = L.pool + (size_t)N * 4;
     L.binHi = L.binCount + (size_t)N * L.maxBins * 4;
     L.binLoInv = L.binHi + (size_t)N * L.maxBins * 4;
-    L.order = align_up(L.binLoInv + (size_t)N * L.maxBins * 4, 256);
+    L.ctlEnd = L.binLoInv + (size_t)N * L.maxBins * 4;
+    L.poolFinal = align_up(L.ctlEnd, 256);
+    L.order = align_up(L.poolFinal + (size_t)N * 4, 256);
     L.total = align_up(L.order + (size_t)N * L.maxBins * 16, 256);
     return L;
 }
@@ -1114,7 +1123,7 @@ extern "C" size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W)
 extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
                                   int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                                   const uint32_t* peel_depth, uint32_t* depth_out,
-                                  void* scratch, size_t scratch_bytes,
+                                  void* scratch, size_t scratch_bytes, int scratch_clean,
                                   float* out, float* out_db, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1167,22 +1176,25 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         const int totalBins = N * binsX * binsY;
         sp.binCount = binCount; sp.binsX = binsX; sp.binsY = binsY;
         sp.binHi = binHi; sp.binLoInv = binLoInv;
-        // pool cursors, bin counts and bin slot ranges are adjacent: one memset clears them all
-        NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)N * 4 + 3 * (size_t)N * L.maxBins * 4, stream));
+        int* poolFinal = (int*)(sb + L.poolFinal);
+        const int bpi = (max_tri + 255) / 256;
+        // Every call leaves the control block zeroed (k_order); it is cleared here only when the caller
+        // cannot vouch for that (first use of the buffer, another layout, a failed call).
+        if (!scratch_clean && tx == 0 && ty == 0)                  // later viewport tiles inherit the clean block from the tile before
+            NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, L.ctlEnd - L.pool, stream));
         {
             ProfileScope ps("raster_setup", stream);
-            const int bpi = (max_tri + 255) / 256;
             hipLaunchKernelGGL(k_setup, dim3((unsigned)((((long long)bpi * N + 7) / 8) * 8)), dim3(256), 0, stream, sp, bpi);
         }
         NVDR_LAUNCH_CHECK();
         {
             ProfileScope ps("raster_order", stream);
-            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, order, totalBins);
+            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, N, order, totalBins);
         }
         NVDR_LAUNCH_CHECK();
 
         FineParams fp;
-        fp.rec = rec; fp.bbox = bbox; fp.poolCount = pool; fp.ranges = ranges; fp.pos = pos; fp.tri = tri;
+        fp.rec = rec; fp.bbox = bbox; fp.poolFinal = poolFinal; fp.ranges = ranges; fp.pos = pos; fp.tri = tri;
         fp.instance = sp.instance; fp.N = N; fp.V = V; fp.T = T; fp.maxTri = max_tri; fp.poolBase = L.poolBase; fp.slots = L.slots;
         fp.W = W; fp.H = H; fp.Wp = Wp; fp.Hp = Hp; fp.vp = vp;
         fp.binsX = binsX; fp.binsY = binsY; fp.totalBins = totalBins;

@@ -97,13 +97,22 @@ class RasterizeCRStateWrapper:
     def __init__(self, cuda_device_idx):
         self.cuda_device_idx = int(cuda_device_idx)
         self.scratch = None
+        self.clean_layout = None
         self.depth = None        # current depth surface  [N,Hp,Wp] int32 (u32 bits)
         self.peel = None         # previous layer's depth surface
 
-    def get_scratch(self, nbytes, device):
+    def get_scratch(self, nbytes, device, layout):
+        """Returns (buffer, clean): `clean` tells the library that the buffer's control block is as this
+        context's previous successful call with the same layout left it (include/nvdr_hip.h)."""
         if self.scratch is None or self.scratch.numel() < nbytes or self.scratch.device != device:
             self.scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        return self.scratch
+            self.clean_layout = None
+        clean = self.clean_layout == layout
+        self.clean_layout = None                  # re-armed by mark_clean() once the call has succeeded
+        return self.scratch, clean
+
+    def mark_clean(self, layout):
+        self.clean_layout = layout
 
     def depth_surfaces(self, shape, device, swap):
         """Returns (peel_in or None, depth_out); mirrors swapDepthAndPeel (RasterImpl.cpp:123-130)."""
@@ -152,7 +161,8 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
         out = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         out_db = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         nbytes = lib.nvdr_rasterize_scratch_bytes(depth, max_tri, height, width)
-        scratch = state.get_scratch(nbytes, dev)
+        layout = (depth, max_tri, height, width)
+        scratch, clean = state.get_scratch(nbytes, dev, layout)
 
         # Depth surfaces exist only while peeling (peeling_idx >= 0); layer k > 0 reads layer k-1's.
         peel_in = depth_out = None
@@ -162,9 +172,10 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
         rc = lib.nvdr_rasterize_fwd(pos.data_ptr(), tri.data_ptr(), _capi.ptr(ranges_dev),
                                     int(instance_mode), depth, V, T, max_tri, height, width,
                                     _capi.ptr(peel_in), _capi.ptr(depth_out),
-                                    scratch.data_ptr(), scratch.numel(),
+                                    scratch.data_ptr(), scratch.numel(), int(clean),
                                     out.data_ptr(), out_db.data_ptr(), _stream(dev))
     _capi.check(rc, fn)
+    state.mark_clean(layout)
     return out, out_db
 
 

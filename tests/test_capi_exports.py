@@ -36,7 +36,8 @@ def test_binding_table_matches_header():
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.nvdr_abi_version() >= 1
+    from nvdiffrast_amd import _capi
+    assert lib.nvdr_abi_version() == _capi.ABI_VERSION
     assert isinstance(lib.nvdr_last_error(), bytes)
 
 
@@ -50,7 +51,7 @@ def test_scratch_query_is_pure_host_code(lib):
 
 def test_bad_arguments_are_rejected_before_any_launch(lib):
     # Null pointers / empty shapes must come back as NVDR_ERR_ARG with a message, not crash.
-    rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, None, None, None)
+    rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, 0, None, None, None)
     assert rc == 1
     assert b"null pointer" in lib.nvdr_last_error()
     rc = lib.nvdr_interpolate_fwd(None, None, None, None, 1, 1, 1, 3, 4, 1, 8, 8, 0, None, 0, None, None, None)
