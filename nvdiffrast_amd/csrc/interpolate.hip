@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 // The reference issues 3*A atomics per pixel behind a __match_any_sync coalescer
 // (interpolate.cu:198-210, common.h:205-216).  Table size comes from the host (dynamic LDS).
 constexpr int kIpBlockW = 64;
-constexpr int kIpBlockH = 32;
-constexpr int kIpThreads = 512;
+constexpr int kIpBlockH = 16;
+constexpr int kIpThreads = 256;
 constexpr int kIpRowsPerWave = 4;
 
 struct IpPixel { int tri; float b0, b1; };
@@ -381,9 +381,9 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
     const long long total = (long long)gx * gy * N;
     NVDR_REQUIRE(total < (1ll << 30), "interpolate_grad: too many pixel blocks");
     dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kIpThreads);
-    // LDS vertex table: as many power-of-two slots as fit in 40 KiB, at most 1024.
-    int slots = 1024;
-    while (slots > 32 && (size_t)slots * (8 * A + 4) > 40 * 1024) slots >>= 1;
+    // LDS vertex table: as many power-of-two slots as fit in 20 KiB (8 workgroups per CU), at most 512.
+    int slots = 512;
+    while (slots > 32 && (size_t)slots * (8 * A + 4) > 20 * 1024) slots >>= 1;
     const size_t lds = (size_t)slots * (8 * A + 4) + 16;
     NVDR_REQUIRE(lds <= 64 * 1024, "interpolate_grad: too many attributes (%d) for the LDS accumulator", A);
     const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);

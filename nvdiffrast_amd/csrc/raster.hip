@@ -884,10 +884,10 @@ struct GradParams {
 // Work order: block b runs on XCD b % 8 (observed placement, speed only); an image's blocks are
 // given to one XCD so that its vertices / indices are fetched into one L2.
 constexpr int kGradBlockW = 64;
-constexpr int kGradBlockH = 32;
-constexpr int kGradThreads = 512;
+constexpr int kGradBlockH = 16;
+constexpr int kGradThreads = 256;
 constexpr int kGradRowsPerWave = 4;
-constexpr int kGradSlots = 1024;
+constexpr int kGradSlots = 512;
 
 struct PixelGrad { int tri, vi0, vi1, vi2; float g[9]; };
 
