@@ -4,7 +4,7 @@
 //  k_interp_fwd   pure streaming: pixels are taken in linear order (one lane = one pixel,
 //                 a wave = 64 consecutive pixels = 1 KiB of rast per load instruction);
 //                 the three vertex attribute rows are gathered from L2.
-//  k_interp_grad  one workgroup per 64x32 pixel block streaming whole rows; attribute gradients
+//  k_interp_grad  one workgroup per 64x16 pixel block streaming whole rows; attribute gradients
 //                 are summed over triangle runs in the wave, accumulated per vertex in an LDS
 //                 fixed-point hash table (ds_add_u64) and flushed as one hardware f32 atomic per
 //                 (vertex, attribute) per block.
@@ -97,8 +97,11 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 
 // ---- backward (interpolate.cu:131-274) -------------------------------------------------
 
-// Workgroup = 64 x 32 pixel block of one image, 8 waves, each wave owning four 64-pixel rows
-// (1 KiB coalesced accesses, four rows in flight).  Two phases around one barrier:
+// Workgroup = 64 x 16 pixel block of one image, 4 waves, each wave owning four 64-pixel rows
+// (1 KiB coalesced accesses).  Small workgroups on purpose: the two phases meet at a barrier, and
+// eight 4-wave groups per CU overlap one group's memory phase with another's LDS phase better than
+// four 8-wave groups did (0.149 -> 0.144 ms; 2-wave groups lose again to the extra flushes).
+// Two phases around one barrier:
 //   A  per pixel: gradients w.r.t. the barycentrics (and their pixel differentials) are written
 //      out; the largest attribute-gradient contribution of the block is published (it fixes the
 //      fixed-point scale of the LDS accumulator, nvdr_device.hpp);

@@ -874,8 +874,8 @@ struct GradParams {
     int dbg;
 };
 
-// Workgroup = 64 x 32 pixel block of one image, 8 waves, each wave owning four 64-pixel rows
-// (1 KiB coalesced loads of rast / dy, all four rows in flight together).  The per-pixel
+// Workgroup = 64 x 16 pixel block of one image, 4 waves, each wave owning four 64-pixel rows
+// (1 KiB coalesced loads of rast / dy).  The per-pixel
 // gradients stay in registers between the two phases:
 //   A  compute them, publish the block's largest magnitude (fixes the fixed-point scale);
 //   B  sum them over runs of equal triangle id inside the wave (RunScan), add the run totals to
