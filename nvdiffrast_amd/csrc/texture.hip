@@ -526,8 +526,10 @@ struct PatchTable {
     int groups, C;
 
     __device__ __forceinline__ void clear(int tid, int nthreads) {
-        for (int i = tid; i < groups; i += nthreads) keys[i] = 0ull;
-        for (int i = tid; i < groups * 16 * C; i += nthreads) vals[i] = 0;
+        // keys and vals are contiguous and 16-byte aligned (groups is a power of two >= 16): 16-byte stores
+        uint4* q = (uint4*)keys;
+        const int n16 = (groups * 8 + groups * 64 * C) >> 4;
+        for (int i = tid; i < n16; i += nthreads) q[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     static __device__ __forceinline__ unsigned long long key_of(int level, int x, int y) {
         return ((unsigned long long)(level + 1) << 58) | ((unsigned long long)(unsigned)(y >> 1) << 29) | (unsigned long long)(unsigned)(x >> 3);
@@ -555,11 +557,12 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     const int C = C_CT > 0 ? C_CT : p.channels;          // compile-time channel count for the common cases: the loops unroll
     PatchTable tab{(unsigned long long*)s_mem, (int*)((unsigned long long*)s_mem + groups), groups, C};
-    uint32_t* s_max = (uint32_t*)(tab.vals + (size_t)groups * 16 * C);
+    uint32_t* s_max = (uint32_t*)(tab.vals + (size_t)groups * 16 * C);     // [0] block max, [1] number of used patches
+    int* s_used = (int*)(s_max + 4);                                        // [groups] indices of the used patches (flush)
     int px = 0, py = 0, pz = 0; bool inside;
     if (!tex_pixel(p, px, py, pz, inside)) return;
     if (groups > 0 && !(p.dbg & 2048)) tab.clear(threadIdx.x, 256);
-    if (threadIdx.x == 0) *s_max = 0u;
+    if (threadIdx.x == 0) { s_max[0] = 0u; s_max[1] = 0u; }
     __syncthreads();
 
     const int tz = (p.texDepth == 1) ? 0 : pz;
@@ -690,7 +693,22 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
                 sclu1 = (float)level_dim(p.texW, level1); sclv1 = (float)level_dim(p.texH, level1);
                 if (second) slots_of(q1, level1, sl1);
             }
+            // Texel values for the uv gradients: with a compile-time channel count all eight taps are fetched
+            // here as whole texels (one vector load each, all in flight across the table work below) instead
+            // of channel by channel inside the loop (24 dependent scalar gathers for RGB).
+            constexpr bool kPrefetch = (C_CT > 0) && !CUBE;
+            constexpr int CMAX = C_CT > 0 ? C_CT : 1;
+            float ta[4][CMAX], tb[4][CMAX];
+            if (kPrefetch) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) load_texel<C_CT>(ta[k], pIn0, q0.tc[k], C);
+                if (second) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) load_texel<C_CT>(tb[k], pIn1, q1.tc[k], C);
+                }
+            }
             const RunScan rs = run_of(q0, level0, q1, level1, second);
+#pragma unroll
             for (int c = 0; c < C; c++) {
                 const float d = pDy[c];
                 const float d0 = kTri ? (1.f - flevel) * d : d;
@@ -712,14 +730,16 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
                     }
                 }
                 float a[4];
-                fetch_quad(pIn0, q0, C, c, a);
+                if (kPrefetch) { a[0] = ta[0][c % CMAX]; a[1] = ta[1][c % CMAX]; a[2] = ta[2][c % CMAX]; a[3] = ta[3][c % CMAX]; }
+                else fetch_quad(pIn0, q0, C, c, a);
                 const float ad = (a[3] + a[0] - a[1] - a[2]);
                 gu += d0 * ((a[1] - a[0]) + q0.fv * ad) * sclu0;
                 gv += d0 * ((a[2] - a[0]) + q0.fu * ad) * sclv0;
                 if (second) {
                     const float dd1 = flevel * d;
                     float b[4];
-                    fetch_quad(pIn1, q1, C, c, b);
+                    if (kPrefetch) { b[0] = tb[0][c % CMAX]; b[1] = tb[1][c % CMAX]; b[2] = tb[2][c % CMAX]; b[3] = tb[3][c % CMAX]; }
+                    else fetch_quad(pIn1, q1, C, c, b);
                     const float bd = (b[3] + b[0] - b[1] - b[2]);
                     gu += dd1 * ((b[1] - b[0]) + q1.fv * bd) * sclu1;
                     gv += dd1 * ((b[2] - b[0]) + q1.fu * bd) * sclv1;
@@ -752,16 +772,22 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     if (direct || (p.dbg & 2048)) return;
 
     // ---- flush: consecutive lanes take consecutive (texel, channel) entries of a patch row ---------
+    // Only the patches that were claimed are visited (a 16x16-pixel block touches a few dozen of the table's
+    // patches, a background block one or two): scanning the whole table cost more instructions than the
+    // rest of the kernel.
+    __syncthreads();
+    for (int g = threadIdx.x; g < groups; g += 256)
+        if (tab.keys[g] != 0ull) s_used[atomicAdd(&s_max[1], 1u)] = g;
     __syncthreads();
     const int perGroup = 16 * C;
-    const int n = groups * perGroup;
+    const int n = (int)s_max[1] * perGroup;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const int g = i / perGroup;
+        const int u = i / perGroup;
+        const int g = s_used[u];
         const unsigned long long key = tab.keys[g];
-        if (key == 0ull) continue;
-        const int t = tab.vals[i];
+        const int r = i - u * perGroup;
+        const int t = tab.vals[g * perGroup + r];
         if (t == 0) continue;
-        const int r = i - g * perGroup;
         const int tx = r / C, c = r - tx * C;
         const int level = (int)(key >> 58) - 1;
         const int x = (int)(key & 0x1FFFFFFFull) * 8 + (tx & 7);
@@ -1026,9 +1052,9 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     // six workgroups share a CU (the kernel is latency bound: occupancy matters more than table size);
     // none (direct atomics) when even 16 patches do not fit.
     int groups = 512;
-    while (groups >= 16 && (size_t)groups * (8 + 64 * (size_t)C) + 16 > 26 * 1024) groups >>= 1;
+    while (groups >= 16 && (size_t)groups * (12 + 64 * (size_t)C) + 16 > 26 * 1024) groups >>= 1;
     if (groups < 16 || (debug_flags() & 256)) groups = 0;
-    const size_t lds = (size_t)groups * (8 + 64 * (size_t)C) + 16;
+    const size_t lds = (size_t)groups * (12 + 64 * (size_t)C) + 16;        // keys 8 B + 16 texels x C sums + used-list entry 4 B per patch
     {
         ProfileScope ps("tex_grad", stream);
 #define NVDR_TEX_GRAD_C(FILTER, BO, CUBE, CC) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, CUBE, CC>), grid, dim3(256), lds, stream, p, groups)
