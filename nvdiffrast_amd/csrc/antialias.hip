@@ -166,11 +166,12 @@ __global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p, int 
 
 __device__ __forceinline__ void swapf(float& a, float& b) { const float t = a; a = b; b = t; }
 
-__global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
+// One work item: silhouette test and edge crossing; writes the blend back into the item and returns it
+// (0 = no blend) with the two pixel indices.
+__device__ __forceinline__ float aa_analyse_item(const AAParams& p, int item_idx, int& o_pix0, int& o_pix1)
 {
 #pragma clang fp contract(off)
-    const int workCount = p.work[0].x;
-    for (int item_idx = blockIdx.x * 256 + threadIdx.x; item_idx < workCount; item_idx += gridDim.x * 256) {
+    {
         int4* pItem = p.work + item_idx + 1;
         const int4 item = *pItem;
         int px = item.x, py = item.y;
@@ -187,13 +188,13 @@ __global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
         int tri = (tri0 >= 0) ? tri0 : tri1;
         if (tri0 >= 0 && tri1 >= 0) tri = (zt0.x < zt1.x) ? tri0 : tri1;
         if (tri == tri1) { px += 1 - d; py += d; }
-        if (tri < 0 || tri >= p.numTriangles) continue;
+        if (tri < 0 || tri >= p.numTriangles) return 0.f;
 
         int vi[3];
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < 3; k++) { vi[k] = p.tri[tri * 3 + k]; bad |= (vi[k] < 0 || vi[k] >= p.numVertices); }
-        if (bad) continue;
+        if (bad) return 0.f;
 
         // Triangle corners and, per edge, the vertex across it in the neighbouring triangle (the corner
         // itself when the edge has no neighbour: always a silhouette), projected to pixel units
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
             const float wing = (x[i] - ox[k]) * (y[j] - oy[k]) - (x[j] - ox[k]) * (y[i] - oy[k]);
             sil[k] = same_sign(wing, bb);
         }
-        if (!(sil[0] || sil[1] || sil[2])) continue;
+        if (!(sil[0] || sil[1] || sil[2])) return 0.f;
 
         // Work in a frame where the pixel pair is horizontal (:330-336), then find the edge that
         // crosses the segment between the two pixel centres nearest to this pixel (:338-359).
@@ -248,100 +249,147 @@ __global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
         if (dc > -eps && dc < 1.f + eps) {
             dc = fminf(fmaxf(dc, 0.f), 1.f);
             const float alpha = ds * (.5f - dc);
-            const float* pColor0 = p.color + pixel0 * p.channels;
-            const float* pColor1 = p.color + pixel1 * p.channels;
-            float* pOutput = p.output + (alpha > 0.f ? pixel0 : pixel1) * p.channels;
-            for (int i = 0; i < p.channels; i++) atomic_add_f32(&pOutput[i], alpha * (pColor1[i] - pColor0[i]));
-
             unsigned flags = (unsigned)pz << 16;
             flags |= (unsigned)di;
             flags |= (unsigned)d << 2;
             flags |= ((unsigned)__float_as_int(ds) >> 31) << 3;
             ((int2*)pItem)[1] = make_int2((int)flags, __float_as_int(alpha));
+            o_pix0 = (int)pixel0; o_pix1 = (int)pixel1;
+            return alpha;
+        }
+    }
+    return 0.f;
+}
+
+// The blend itself is emitted transposed (see k_aa_grad): consecutive lanes add the consecutive channels of
+// one pixel, so the C atomics of a pair reach memory as one transaction instead of C.
+__global__ __launch_bounds__(256) void k_aa_analysis(const AAParams p)
+{
+#pragma clang fp contract(off)
+    __shared__ float s_alpha[256];
+    __shared__ int s_pix[256][2];
+    const int workCount = p.work[0].x;
+    const int C = p.channels;
+    for (int base = blockIdx.x * 256; base < workCount; base += gridDim.x * 256) {      // uniform trip count: barriers inside
+        const int item_idx = base + threadIdx.x;
+        int p0 = 0, p1 = 0;
+        const float alpha = (item_idx < workCount) ? aa_analyse_item(p, item_idx, p0, p1) : 0.f;
+        __syncthreads();                                                   // previous round's readers are done
+        s_alpha[threadIdx.x] = alpha; s_pix[threadIdx.x][0] = p0; s_pix[threadIdx.x][1] = p1;
+        __syncthreads();
+        for (int f = threadIdx.x; f < 256 * C; f += 256) {
+            const int j = f / C, c = f - j * C;
+            const float al = s_alpha[j];
+            if (al == 0.f) continue;
+            const size_t q0 = (size_t)s_pix[j][0] * C + c, q1 = (size_t)s_pix[j][1] * C + c;
+            atomic_add_f32(p.output + (al > 0.f ? q0 : q1), al * (p.color[q1] - p.color[q0]));
         }
     }
 }
 
 // ---- gradients (antialias.cu:387-556) ---------------------------------------------------------------
 
+// Atomics are what this kernel costs (a blended pixel pair sends 2C colour and 6 position updates, and a
+// scattered f32 atomic is one memory transaction per LANE: 12 per pair for RGB).  The per-pair values are
+// therefore staged in LDS and emitted transposed: consecutive lanes take the consecutive channels of one
+// pixel, or the x, y, (z,) w of one vertex, so each 12- or 16-byte group reaches memory as one transaction.
+struct AAStage { float alpha; int pix0, pix1; int vert[2]; float g[2][3]; };
+
 __global__ __launch_bounds__(256) void k_aa_grad(const AAParams p)
 {
 #pragma clang fp contract(off)
+    __shared__ AAStage s_st[256];
     const int workCount = p.work[0].x;
-    for (int item_idx = blockIdx.x * 256 + threadIdx.x; item_idx < workCount; item_idx += gridDim.x * 256) {
-        const int4 item = p.work[item_idx + 1];
-        if (item.w == 0) continue;                                    // bits of alpha: no effect
-
-        int px = item.x, py = item.y;
-        const int pz = (int)(((unsigned)item.z) >> 16);
-        const int d = (item.z >> 2) & 1;
-        const float alpha = __int_as_float(item.w);
-        const int tri1 = (item.z >> 3) & 1;
-        const int di = item.z & 3;
-        const size_t pixel0 = (size_t)px + (size_t)p.width * (py + (size_t)p.height * pz);
-        const size_t pixel1 = pixel0 + (d ? (size_t)p.width : 1);
-        const int tri = float_to_triidx(p.rast[((tri1 ? pixel1 : pixel0) << 2) + 3]) - 1;
-        if (tri1) { px += 1 - d; py += d; }
-        if (tri < 0 || tri >= p.numTriangles) continue;
-
-        float* pGrad0 = p.gradColor + pixel0 * p.channels;
-        float* pGrad1 = p.gradColor + pixel1 * p.channels;
-        const float* pDy = p.dy + (alpha > 0.f ? pixel0 : pixel1) * p.channels;
-        const float* pColor0 = p.color + pixel0 * p.channels;
-        const float* pColor1 = p.color + pixel1 * p.channels;
-
-        float dd = 0.f;
-        for (int i = 0; i < p.channels; i++) {
-            const float dy = pDy[i];
-            if (dy != 0.f) {
-                dd += dy * (pColor1[i] - pColor0[i]);
-                const float v = alpha * dy;
-                atomic_add_f32(&pGrad0[i], -v);
-                atomic_add_f32(&pGrad1[i], v);
+    const int C = p.channels;
+    for (int base = blockIdx.x * 256; base < workCount; base += gridDim.x * 256) {      // uniform trip count: barriers inside
+        const int item_idx = base + threadIdx.x;
+        AAStage st;
+        st.alpha = 0.f; st.pix0 = st.pix1 = 0; st.vert[0] = st.vert[1] = -1;
+        st.g[0][0] = st.g[0][1] = st.g[0][2] = st.g[1][0] = st.g[1][1] = st.g[1][2] = 0.f;
+        const int4 item = (item_idx < workCount) ? p.work[item_idx + 1] : make_int4(0, 0, 0, 0);
+        if (item.w != 0) {                                                // bits of alpha: 0 = no effect
+            int px = item.x, py = item.y;
+            const int pz = (int)(((unsigned)item.z) >> 16);
+            const int d = (item.z >> 2) & 1;
+            const float alpha = __int_as_float(item.w);
+            const int tri1 = (item.z >> 3) & 1;
+            const int di = item.z & 3;
+            const size_t pixel0 = (size_t)px + (size_t)p.width * (py + (size_t)p.height * pz);
+            const size_t pixel1 = pixel0 + (d ? (size_t)p.width : 1);
+            const int tri = float_to_triidx(p.rast[((tri1 ? pixel1 : pixel0) << 2) + 3]) - 1;
+            if (tri1) { px += 1 - d; py += d; }
+            if (tri >= 0 && tri < p.numTriangles) {
+                st.alpha = alpha; st.pix0 = (int)pixel0; st.pix1 = (int)pixel1;      // colour part: emitted transposed below
+                const float* pDy = p.dy + (alpha > 0.f ? pixel0 : pixel1) * C;
+                const float* pColor0 = p.color + pixel0 * C;
+                const float* pColor1 = p.color + pixel1 * C;
+                float dd = 0.f;
+                for (int i = 0; i < C; i++) {
+                    const float dy = pDy[i];
+                    if (dy != 0.f) dd += dy * (pColor1[i] - pColor0[i]);
+                }
+                // The blend weight is alpha = +-(1/2 - c) with c = x1 - y1 (x2 - x1) / (y2 - y1): the crossing of
+                // the silhouette edge (v1, v2) with the row through the pixel centre, in the frame where the
+                // pixel pair is horizontal (:338-365).  dL/dc = -dd; the adjoint runs from c back through the
+                // screen-space edge ends to the clip-space vertices (:508-546).  1 / (y2 - y1) is regularised by
+                // a signed 1e-3 pixel; saturated blends (|alpha| >= 1/2) carry no position gradient.
+                const int e1 = (di + 1) % 3, e2 = (di + 2) % 3;
+                const int ve[2] = {p.tri[3 * tri + e1], p.tri[3 * tri + e2]};
+                if (dd != 0.f && !(ve[0] < 0 || ve[0] >= p.numVertices || ve[1] < 0 || ve[1] >= p.numVertices)) {
+                    const size_t vbase = p.instance ? (size_t)pz * p.numVertices : 0;
+                    // axis a = direction of the pixel pair (0: x, 1: y), b = the other one
+                    const float half_a = d ? p.yh : p.xh, half_b = d ? p.xh : p.yh;
+                    const float fa = (float)(d ? py : px) + .5f - half_a;
+                    const float fb = (float)(d ? px : py) + .5f - half_b;
+                    float ca[2], cb[2], rw[2], sa[2], sb[2];           // clip-space coords, 1/w, screen-space coords of the two ends
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const float4 v = ((const float4*)p.pos)[vbase + ve[k]];
+                        ca[k] = d ? v.y : v.x; cb[k] = d ? v.x : v.y;
+                        rw[k] = 1.f / v.w;
+                        sa[k] = ca[k] * rw[k] * half_a - fa;
+                        sb[k] = cb[k] * rw[k] * half_b - fb;
+                    }
+                    const float da = sa[1] - sa[0], db = sb[1] - sb[0];
+                    const float cross = sa[0] * db - sb[0] * da;
+                    const float ib = 1.f / (db + copysignf(1e-3f, db));
+                    const float c = cross * ib;
+                    // adjoints of the screen-space ends: d c / d sa0 = sb1 / db, d c / d sa1 = -sb0 / db,
+                    //                                    d c / d sb0 = (c - sa1) / db, d c / d sb1 = -(c - sa0) / db
+                    const float gc = (fabsf(alpha) >= 0.5f) ? 0.f : -dd;
+                    const float gsa[2] = {gc * ib * sb[1], -gc * ib * sb[0]};
+                    const float gsb[2] = {gc * ib * (c - sa[1]), -gc * ib * (c - sa[0])};
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        // s = clip * (1/w) * half - f
+                        const float ga = gsa[k] * rw[k] * half_a, gb = gsb[k] * rw[k] * half_b;
+                        const float gw = -(ca[k] * ga + cb[k] * gb) * rw[k];
+                        st.vert[k] = (int)(vbase + ve[k]);
+                        st.g[k][0] = d ? gb : ga; st.g[k][1] = d ? ga : gb; st.g[k][2] = gw;
+                    }
+                }
             }
         }
-        if (dd == 0.f) continue;
-
-        // The blend weight is alpha = +-(1/2 - c) with c = x1 - y1 (x2 - x1) / (y2 - y1): the crossing of
-        // the silhouette edge (v1, v2) with the row through the pixel centre, in the frame where the
-        // pixel pair is horizontal (:338-365).  dL/dc = -dd; the adjoint runs from c back through the
-        // screen-space edge ends to the clip-space vertices (:508-546).  1 / (y2 - y1) is regularised by
-        // a signed 1e-3 pixel; saturated blends (|alpha| >= 1/2) carry no position gradient.
-        const int e1 = (di + 1) % 3, e2 = (di + 2) % 3;
-        int ve[2] = {p.tri[3 * tri + e1], p.tri[3 * tri + e2]};
-        if (ve[0] < 0 || ve[0] >= p.numVertices || ve[1] < 0 || ve[1] >= p.numVertices) continue;
-        const size_t vbase = p.instance ? (size_t)pz * p.numVertices : 0;
-        // axis a = direction of the pixel pair (0: x, 1: y), b = the other one
-        const float half_a = d ? p.yh : p.xh, half_b = d ? p.xh : p.yh;
-        const float fa = (float)(d ? py : px) + .5f - half_a;
-        const float fb = (float)(d ? px : py) + .5f - half_b;
-        float ca[2], cb[2], rw[2], sa[2], sb[2];               // clip-space coords, 1/w, screen-space coords of the two ends
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const float4 v = ((const float4*)p.pos)[vbase + ve[k]];
-            ca[k] = d ? v.y : v.x; cb[k] = d ? v.x : v.y;
-            rw[k] = 1.f / v.w;
-            sa[k] = ca[k] * rw[k] * half_a - fa;
-            sb[k] = cb[k] * rw[k] * half_b - fb;
+        __syncthreads();                                                   // previous round's readers are done
+        s_st[threadIdx.x] = st;
+        __syncthreads();
+        // colour: lane -> (pair, side, channel); the reference skips exact-zero upstream values (:449-462)
+        const int twoC = 2 * C;
+        for (int f = threadIdx.x; f < 256 * twoC; f += 256) {
+            const int j = f / twoC, r = f - j * twoC;
+            const int side = r >= C ? 1 : 0, c = r - side * C;
+            const float alpha = s_st[j].alpha;
+            if (alpha == 0.f) continue;
+            const int p0 = s_st[j].pix0, p1 = s_st[j].pix1;
+            const float dy = p.dy[(size_t)(alpha > 0.f ? p0 : p1) * C + c];
+            if (dy != 0.f) atomic_add_f32(p.gradColor + (size_t)(side ? p1 : p0) * C + c, side ? alpha * dy : -(alpha * dy));
         }
-        const float da = sa[1] - sa[0], db = sb[1] - sb[0];
-        const float cross = sa[0] * db - sb[0] * da;
-        const float ib = 1.f / (db + copysignf(1e-3f, db));
-        const float c = cross * ib;
-        // adjoints of the screen-space ends: d c / d sa0 = sb1 / db, d c / d sa1 = -sb0 / db,
-        //                                    d c / d sb0 = (c - sa1) / db, d c / d sb1 = -(c - sa0) / db
-        const float gc = (fabsf(alpha) >= 0.5f) ? 0.f : -dd;
-        const float gsa[2] = {gc * ib * sb[1], -gc * ib * sb[0]};
-        const float gsb[2] = {gc * ib * (c - sa[1]), -gc * ib * (c - sa[0])};
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            // s = clip * (1/w) * half - f
-            const float ga = gsa[k] * rw[k] * half_a, gb = gsb[k] * rw[k] * half_b;
-            const float gw = -(ca[k] * ga + cb[k] * gb) * rw[k];
-            float* q = p.gradPos + 4 * (vbase + ve[k]);
-            atomic_add_f32(q + 0, d ? gb : ga);
-            atomic_add_f32(q + 1, d ? ga : gb);
-            atomic_add_f32(q + 3, gw);
+        // positions: lane -> (pair, edge end, x|y|z|w); z carries nothing
+        for (int f = threadIdx.x; f < 256 * 8; f += 256) {
+            const int j = f >> 3, k = (f >> 2) & 1, comp = f & 3;
+            const int v = s_st[j].vert[k];
+            if (v < 0 || comp == 2) continue;
+            atomic_add_f32(p.gradPos + 4 * (size_t)v + comp, s_st[j].g[k][comp == 3 ? 2 : comp]);
         }
     }
 }
