@@ -28,7 +28,7 @@ struct ProfileScope {
 //   4/8/16 k_fine (debug instantiation): skip raster / force empty ids / skip output stores
 //   64    k_fine timeline records pair counts instead of phase times (tools/fine_pairs.py)
 //   256   texture grad: no LDS patch table (direct global atomics)
-//   512 / 1024 / 2048  texture grad: skip scatter / slot lookups / table clear+flush (cost splits)
+//   1024 / 2048  texture grad: skip slot lookups / table clear+flush (cost splits)
 int debug_flags();
 // Optional device buffer for in-kernel timestamps (development only; nvdr_debug_buffer()).
 unsigned long long* debug_buffer();

@@ -387,15 +387,16 @@ __device__ __forceinline__ void load_texel(float* dst, const float* base, int tc
 __device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, int& pz, bool& inside)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long blocksPerImage = (long long)p.tilesX * p.tilesY;          // tilesX/Y count 16x16 blocks here
-    const long long total = blocksPerImage * p.n;
-    const long long perXcd = (total + 7) >> 3;
-    const long long j = blockIdx.x >> 3;
-    const long long blk = (long long)(blockIdx.x & 7) * perXcd + j;
+    // 32-bit on purpose (the host checks the block count): a 64-bit division here is ~140 scalar instructions per wave
+    const int blocksPerImage = p.tilesX * p.tilesY;                           // tilesX/Y count 16x16 blocks here
+    const int total = blocksPerImage * p.n;
+    const int perXcd = (total + 7) >> 3;
+    const int j = (int)(blockIdx.x >> 3);
+    const int blk = (int)(blockIdx.x & 7) * perXcd + j;
     inside = false;
     if (j >= perXcd || blk >= total) return false;
-    pz = (int)(blk / blocksPerImage);
-    const int rem = (int)(blk - (long long)pz * blocksPerImage);
+    pz = blk / blocksPerImage;
+    const int rem = blk - pz * blocksPerImage;
     const int by = rem / p.tilesX, bx = rem - by * p.tilesX;
     px = bx * 16 + (wave & 1) * 8 + (lane & 7);
     py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -521,30 +522,31 @@ __global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
 // constant-uv background) cost one global atomic per workgroup instead of one per pixel.
 // The fixed-point scale comes from the block's largest |dy| (every tap weight is in [0,1]).
 struct PatchTable {
-    unsigned long long* keys;     // [groups]  0 = empty
+    uint32_t* keys;               // [groups]  0 = empty
     int* vals;                    // [groups * 16 * C] 32-bit fixed-point sums
     int groups, C;
 
     __device__ __forceinline__ void clear(int tid, int nthreads) {
-        // keys and vals are contiguous and 16-byte aligned (groups is a power of two >= 16): 16-byte stores
-        uint4* q = (uint4*)keys;
-        const int n16 = (groups * 8 + groups * 64 * C) >> 4;
+        // vals then keys, contiguous and 16-byte aligned (groups is a power of two >= 16): 16-byte stores
+        uint4* q = (uint4*)vals;
+        const int n16 = (groups * 64 * C + groups * 4) >> 4;
         for (int i = tid; i < n16; i += nthreads) q[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    static __device__ __forceinline__ unsigned long long key_of(int level, int x, int y) {
-        return ((unsigned long long)(level + 1) << 58) | ((unsigned long long)(unsigned)(y >> 1) << 29) | (unsigned long long)(unsigned)(x >> 3);
+    // (level + 1) << 27 | patch row << 12 | patch column: textures up to 32768 x 65536 texels (the host falls
+    // back to direct atomics beyond that).  32-bit keys: one ds_cmpst_b32 and a 32-bit hash per probe.
+    static __device__ __forceinline__ uint32_t key_of(int level, int x, int y) {
+        return ((uint32_t)(level + 1) << 27) | ((uint32_t)(y >> 1) << 12) | (uint32_t)(x >> 3);
     }
     // Index of texel (x, y) of `level` in vals (in texels, multiply by C) or -1 when the table is full.
     __device__ __forceinline__ int find(int level, int x, int y) const {
-        const unsigned long long key = key_of(level, x, y);
-        unsigned long long k = key;
-        k ^= k >> 29; k *= 0x9E3779B97F4A7C15ull; k ^= k >> 32;
-        unsigned h = (unsigned)k;
+        const uint32_t key = key_of(level, x, y);
+        uint32_t h = key * 0x9E3779B1u;
+        h ^= h >> 15;
 #pragma unroll 1
         for (int probe = 0; probe < 8; probe++) {
-            h &= (unsigned)(groups - 1);
-            const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
-            if (old == 0ull || old == key) return (int)h * 16 + (y & 1) * 8 + (x & 7);
+            h &= (uint32_t)(groups - 1);
+            const uint32_t old = atomicCAS(&keys[h], 0u, key);
+            if (old == 0u || old == key) return (int)h * 16 + (y & 1) * 8 + (x & 7);
             h++;
         }
         return -1;
@@ -556,8 +558,9 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     const int C = C_CT > 0 ? C_CT : p.channels;          // compile-time channel count for the common cases: the loops unroll
-    PatchTable tab{(unsigned long long*)s_mem, (int*)((unsigned long long*)s_mem + groups), groups, C};
-    uint32_t* s_max = (uint32_t*)(tab.vals + (size_t)groups * 16 * C);     // [0] block max, [1] number of used patches
+    // LDS layout: vals [groups*16*C] | keys [groups] | {block max, used count, -, -} | used-patch list [groups]
+    PatchTable tab{(uint32_t*)((int*)s_mem + (size_t)groups * 16 * C), (int*)s_mem, groups, C};
+    uint32_t* s_max = tab.keys + groups;                                    // [0] block max, [1] number of used patches
     int* s_used = (int*)(s_max + 4);                                        // [groups] indices of the used patches (flush)
     int px = 0, py = 0, pz = 0; bool inside;
     if (!tex_pixel(p, px, py, pz, inside)) return;
@@ -599,12 +602,13 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     const bool direct = (groups == 0) || maxBits >= 0x7F800000u; // no table / inf or NaN present: plain f32 atomics
     const FixedScale32 fs(direct ? 0x3F800000u : maxBits);
 
-    // One tap's contribution: LDS table when it has a slot, global atomic otherwise.
-    const bool noScatter = p.dbg & 512;
-    auto scatter = [&](int slot, int level, int tc, int c, float v) {
-        if (noScatter) return;
-        if (slot >= 0) atomicAdd(&tab.vals[(size_t)slot * C + c], fs.to_fixed(v));
-        else atomic_add_f32(p.gradTex[level] + tc * C + c, v);
+    // One tap's contribution goes to the LDS table when the tap has a slot; taps without one (table full, no
+    // table, inf/NaN present) are sent to memory directly under a wave-uniform test, off the common path.
+    auto scatter = [&](int slot, int c, float v) {
+        if (slot >= 0) atomicAdd(&tab.vals[slot * C + c], fs.to_fixed(v));
+    };
+    auto spill = [&](int slot, int level, int tc, int c, float v) {
+        if (tc >= 0 && slot < 0) atomic_add_f32(p.gradTex[level] + tc * C + c, v);
     };
     auto slots_of = [&](const Quad& q, int level, int* sl) {
         // The four taps of a bilinear footprint share patches most of the time: look each patch up once.
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
             }
             if (tc >= 0) {
                 const int sl = direct ? -1 : tab.find(0, x, y);
-                for (int c = 0; c < C; c++) scatter(sl, 0, tc, c, pDy[c]);
+                for (int c = 0; c < C; c++) { scatter(sl, c, pDy[c]); spill(sl, 0, tc, c, pDy[c]); }
             }
         } else {
             float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -708,7 +712,10 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
                 }
             }
             const RunScan rs = run_of(q0, level0, q1, level1, second);
+            int lost = 0;                                        // sign bit: some valid tap (tc >= 0) of this lane has no slot (< 0)
 #pragma unroll
+            for (int k = 0; k < 4; k++) lost |= (~q0.tc[k] & sl0[k]) | (second ? (~q1.tc[k] & sl1[k]) : 0);
+            const bool anyLost = __ballot(lost < 0) != 0ull;
             for (int c = 0; c < C; c++) {
                 const float d = pDy[c];
                 const float d0 = kTri ? (1.f - flevel) * d : d;
@@ -723,10 +730,18 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
                 }
                 if (rs.tail) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (q0.tc[k] >= 0) scatter(sl0[k], level0, q0.tc[k], c, v0[k]);
+                    for (int k = 0; k < 4; k++) scatter(sl0[k], c, v0[k]);
                     if (second) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (q1.tc[k] >= 0) scatter(sl1[k], level1, q1.tc[k], c, v1[k]);
+                        for (int k = 0; k < 4; k++) scatter(sl1[k], c, v1[k]);
+                    }
+                    if (anyLost) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) spill(sl0[k], level0, q0.tc[k], c, v0[k]);
+                        if (second) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) spill(sl1[k], level1, q1.tc[k], c, v1[k]);
+                        }
                     }
                 }
                 float a[4];
@@ -777,21 +792,21 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     // rest of the kernel.
     __syncthreads();
     for (int g = threadIdx.x; g < groups; g += 256)
-        if (tab.keys[g] != 0ull) s_used[atomicAdd(&s_max[1], 1u)] = g;
+        if (tab.keys[g] != 0u) s_used[atomicAdd(&s_max[1], 1u)] = g;
     __syncthreads();
     const int perGroup = 16 * C;
     const int n = (int)s_max[1] * perGroup;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int u = i / perGroup;
         const int g = s_used[u];
-        const unsigned long long key = tab.keys[g];
+        const uint32_t key = tab.keys[g];
         const int r = i - u * perGroup;
         const int t = tab.vals[g * perGroup + r];
         if (t == 0) continue;
         const int tx = r / C, c = r - tx * C;
-        const int level = (int)(key >> 58) - 1;
-        const int x = (int)(key & 0x1FFFFFFFull) * 8 + (tx & 7);
-        const int y = (int)((key >> 29) & 0x1FFFFFFFull) * 2 + (tx >> 3);
+        const int level = (int)(key >> 27) - 1;
+        const int x = (int)(key & 0xFFFu) * 8 + (tx & 7);
+        const int y = (int)((key >> 12) & 0x7FFFu) * 2 + (tx >> 3);
         const int w = level_dim(p.texW, level), h = level_dim(p.texH, level) * (CUBE ? 6 : 1);
         if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
         atomic_add_f32(p.gradTex[level] + ((tz * h + y) * w + x) * C + c, fs.to_float(t));
@@ -916,13 +931,14 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
     p.boundary = boundary; p.channels = C; p.imgW = W; p.imgH = H; p.n = N;
     p.texW = tex_w; p.texH = tex_h; p.texDepth = tex_n;
     p.tilesX = (W + 15) / 16; p.tilesY = (H + 15) / 16;
+    NVDR_REQUIRE((long long)p.tilesX * p.tilesY * N < (1ll << 30), "%s: too many pixel blocks", who);
     p.dbg = debug_flags();
     return NVDR_OK;
 }
 
 static dim3 tex_grid(const TexParams& p)
 {
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.n;
+    const long long blocks = (long long)p.tilesX * p.tilesY * p.n;             // < 2^30: checked in fill_tex_params
     return dim3((unsigned)(((blocks + 7) / 8) * 8));
 }
 
@@ -1052,9 +1068,9 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     // six workgroups share a CU (the kernel is latency bound: occupancy matters more than table size);
     // none (direct atomics) when even 16 patches do not fit.
     int groups = 512;
-    while (groups >= 16 && (size_t)groups * (12 + 64 * (size_t)C) + 16 > 26 * 1024) groups >>= 1;
-    if (groups < 16 || (debug_flags() & 256)) groups = 0;
-    const size_t lds = (size_t)groups * (12 + 64 * (size_t)C) + 16;        // keys 8 B + 16 texels x C sums + used-list entry 4 B per patch
+    while (groups >= 16 && (size_t)groups * (8 + 64 * (size_t)C) + 16 > 26 * 1024) groups >>= 1;
+    if (groups < 16 || tex_w > 32768 || (long long)tex_h * (cube ? 6 : 1) > 65536 || (debug_flags() & 256)) groups = 0;   // key format
+    const size_t lds = (size_t)groups * (8 + 64 * (size_t)C) + 16;         // 16 texels x C sums + key 4 B + used-list entry 4 B per patch
     {
         ProfileScope ps("tex_grad", stream);
 #define NVDR_TEX_GRAD_C(FILTER, BO, CUBE, CC) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, CUBE, CC>), grid, dim3(256), lds, stream, p, groups)
