@@ -37,12 +37,14 @@ __device__ __forceinline__ int diff_index(const InterpParams& p, int i)
 template <int A_CT, bool ENABLE_DA>
 __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 {
-    const size_t HW = (size_t)p.width * p.height;
-    const size_t total = HW * p.depth;
-    const size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (pidx >= total) return;
+    // grid = (blocks per image, images in chunks of 32768): the image index comes from the block index; a 64-bit
+    // pidx / HW per lane was more than half of this kernel's instructions.
+    const unsigned HW = (unsigned)p.width * (unsigned)p.height;
+    const unsigned inImage = blockIdx.x * 256u + threadIdx.x;
+    const int pz = (int)(blockIdx.y + blockIdx.z * 32768u);
+    if (inImage >= HW || pz >= p.depth) return;
+    const size_t pidx = (size_t)pz * HW + inImage;
     const int A = A_CT > 0 ? A_CT : p.numAttr;
-    const int pz = (int)(pidx / HW);
 
     float4 r = ((const float4*)p.rast)[pidx];
     int triIdx = float_to_triidx(r.w) - 1;
@@ -240,9 +242,20 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
         const bool emit = direct ? ok[r] : rs.tail;
         int s0 = -1, s1 = -1, s2 = -1;
         if (emit && !direct) { s0 = tab.find(vi[r][0]); s1 = tab.find(vi[r][1]); s2 = tab.find(vi[r][2]); }
-        auto put = [&](int slot, int vi, int i, float v) {
-            if (slot >= 0) tab.add(slot, i, fs.to_fixed(v));
-            else atomic_add_f32(gattr + (size_t)vi * A + i, v);
+        // Lanes whose three vertices all have slots (the rule) add to the table under ONE test per value triple;
+        // the rest (table full, inf/NaN mode) take the per-vertex path under a wave-uniform test.
+        const bool tabled = emit && (s0 | s1 | s2) >= 0;
+        const bool anyLoose = __ballot(emit && !tabled) != 0ull;
+        auto put3 = [&](int i, float v0, float v1, float v2) {
+            if (tabled) { tab.add(s0, i, fs.to_fixed(v0)); tab.add(s1, i, fs.to_fixed(v1)); tab.add(s2, i, fs.to_fixed(v2)); }
+            if (anyLoose && emit && !tabled) {
+                const int sl[3] = {s0, s1, s2}; const float vv[3] = {v0, v1, v2};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (sl[k] >= 0) tab.add(sl[k], i, fs.to_fixed(vv[k]));
+                    else atomic_add_f32(gattr + (size_t)vi[r][k] * A + i, vv[k]);
+                }
+            }
         };
         const float b0 = ok[r] ? q[r].b0 : 0.f, b1 = ok[r] ? q[r].b1 : 0.f, b2 = ok[r] ? 1.f - q[r].b0 - q[r].b1 : 0.f;
         const size_t pidx = ((size_t)pz * p.height + (row0 + r)) * p.width + px;
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
             else       y = ok[r] ? pdy[i] : 0.f;
             float v0 = b0 * y, v1 = b1 * y, v2 = b2 * y;
             if (!direct) rs.scan3(v0, v1, v2);
-            if (emit) { put(s0, vi[r][0], i, v0); put(s1, vi[r][1], i, v1); put(s2, vi[r][2], i, v2); }
+            put3(i, v0, v1, v2);
         }
         if (ENABLE_DA) {
             float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
                 float dv = d.x * db.z + d.y * db.w;
                 float dw = -du - dv;
                 if (!direct) rs.scan3(du, dv, dw);
-                if (emit) { put(s0, vi[r][0], j, du); put(s1, vi[r][1], j, dv); put(s2, vi[r][2], j, dw); }
+                put3(j, du, dv, dw);
             }
         }
     }
@@ -348,8 +361,8 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
     NVDR_REQUIRE(!enable_da || out_da, "interpolate_fwd: out_da missing");
     NVDR_REQUIRE(!((uintptr_t)out_da & 7), "out_da output tensor not aligned to float2");
     p.out = out; p.outDA = enable_da ? out_da : nullptr;
-    const size_t total = (size_t)N * H * W;
-    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    NVDR_REQUIRE((long long)H * W < (1ll << 31), "interpolate_fwd: image too large");
+    dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)(N < 32768 ? N : 32768), (unsigned)((N + 32767) / 32768)), block(256);
     const float* VECPTR = out;
     {
         ProfileScope ps(enable_da ? "interp_fwd_da" : "interp_fwd", stream);
