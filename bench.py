@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--cpu-items", type=int, default=64, help="items in the CPU-oracle sample")
     ap.add_argument("--gather-images", action="store_true",
                     help="also all-gather the per-item output images to every rank inside the step (off: items stay sharded)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step into one hipGraph and time replays (single GPU only; the default, and the "
+                         "number the driver records, is eager launching)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,12 +114,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = step
+    if args.graph:
+        # No op of the path synchronises the host or allocates at the C-ABI level, so the whole step captures.
+        assert not distributed, "--graph is a single-GPU measurement"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -218,7 +235,8 @@ def main():
                                    "A=%d attrs, rasterize+interpolate fwd+bwd, upstream grad fed to backward directly"
                                    % (N, RES, RES, ATTRS),
                        "batch_per_gpu": N, "resolution": [RES, RES], "triangles": int(tri.shape[0]),
-                       "parallelism": "dp%d (items sharded, shared-attr grad all-reduce)" % world},
+                       "parallelism": "dp%d (items sharded, shared-attr grad all-reduce)" % world,
+                       "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roofline,
             "path_hbm_frac": round((path_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 4),
             "kernels": kernels,
