@@ -205,7 +205,7 @@ __device__ bool snap_cull_setup(const Viewport& vp, const float (*v)[4], SubTri&
 // Record layout (4 x uint4):
 //   q0 = {A0, B0, C0, A1}   q1 = {B1, C1, A2, B2}   q2 = {C2, zx, zy, zb}   q3 = {id, aabb, 0, 0}
 // with E_e(X,Y) = C_e + X*A_e + Y*B_e >= 0  <=>  pixel (X,Y) is inside edge e.
-__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id, int* s_hist, uint4* stage)
+__device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id, int* s_hist, uint4* stage, uint32_t* boxStage)
 {
     const Viewport& vp = p.vp;
     int bx = (vp.vpw - 1) << (kSpLog2 - 1);
@@ -215,7 +215,7 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     int x0 = max((lox + bx + 15) >> 4, 0), x1 = min((hix + bx) >> 4, vp.vpw - 1);
     int y0 = max((loy + by + 15) >> 4, 0), y1 = min((hiy + by) >> 4, vp.vph - 1);
     size_t so = (size_t)n * p.slots + slot;
-    if (x0 > x1 || y0 > y1) { p.bbox[so] = kEmptyBox; return; }
+    if (x0 > x1 || y0 > y1) { if (boxStage) *boxStage = kEmptyBox; else p.bbox[so] = kEmptyBox; return; }
     uint32_t box = (uint32_t)(x0 >> 3) | ((uint32_t)(y0 >> 3) << 8) | ((uint32_t)(x1 >> 3) << 16) | ((uint32_t)(y1 >> 3) << 24);
     for (int by_ = y0 >> 6; by_ <= (y1 >> 6); by_++)
         for (int bx_ = x0 >> 6; bx_ <= (x1 >> 6); bx_++)
@@ -246,7 +246,7 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     r[1] = make_uint4(B[1], C[1], A[2], B[2]);
     r[2] = make_uint4(C[2], s.zx, s.zy, s.zb);
     r[3] = make_uint4((uint32_t)id, box, 0u, 0u);
-    p.bbox[so] = box;
+    if (boxStage) *boxStage = box; else p.bbox[so] = box;         // direct slots: AABBs leave as whole rows too (k_setup)
 }
 
 // Util.inl:101-130.
@@ -282,7 +282,7 @@ __device__ int clip_poly_plane(float* out, const float* in, int n_in, float f0, 
 // path stays small.
 // pool_slot < 0: only count the surviving sub-triangles (returned); otherwise emit them, the first into
 // slot0 and the rest into pool slots pool_slot, pool_slot + 1, ... (reserved by the caller).
-__device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist, uint4* stage, int pool_slot)
+__device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist, uint4* stage, uint32_t* boxStage, int pool_slot)
 {
 #pragma clang fp contract(off)
     float d1[4], d2[4], bary[18], tmp[18];
@@ -315,26 +315,28 @@ __device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0
     }
 
     if (pool_slot < 0) return ns;
-    if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return 0; }
-    emit_record(p, n, slot0, st[0], id, s_hist, stage);
+    if (ns == 0) { if (boxStage) *boxStage = kEmptyBox; else p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return 0; }
+    emit_record(p, n, slot0, st[0], id, s_hist, stage, boxStage);
     for (int k = 1; k < ns; k++)                             // cannot exceed slots - poolBase by construction
-        emit_record(p, n, p.poolBase + pool_slot + k - 1, st[k], id, s_hist, nullptr);
+        emit_record(p, n, p.poolBase + pool_slot + k - 1, st[k], id, s_hist, nullptr, nullptr);
     return ns;
 }
 
 // `clipq` != nullptr: triangles that need the clipper are only queued (their block processes them
 // densely afterwards, see k_setup).  `clipq` == nullptr: run the clipper for triangle i -- counting the
 // sub-triangles when pool_slot < 0, emitting them otherwise.  Returns the sub-triangle count.
-__device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage, int* clipq, int* clipn, int pool_slot = -1)
+__device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage, uint32_t* boxStage, int* clipq, int* clipn, int pool_slot = -1)
 {
 #pragma clang fp contract(off)
     int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
     if (i >= cnt) return 0;
     size_t so = (size_t)n * p.slots + i;
+    // The slot's AABB: staged in LDS for the block's own (direct) slots, in place otherwise.
+    auto empty_box = [&]() { if (boxStage) *boxStage = kEmptyBox; else p.bbox[so] = kEmptyBox; };
     int t = i + (p.instance ? 0 : p.ranges[2 * n]);
-    if ((uint32_t)t >= (uint32_t)p.T) { p.bbox[so] = kEmptyBox; return 0; }           // :228-233
+    if ((uint32_t)t >= (uint32_t)p.T) { empty_box(); return 0; }                       // :228-233
     uint32_t i0 = (uint32_t)p.tri[t * 3 + 0], i1 = (uint32_t)p.tri[t * 3 + 1], i2 = (uint32_t)p.tri[t * 3 + 2];
-    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) { p.bbox[so] = kEmptyBox; return 0; } // :241-248
+    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) { empty_box(); return 0; } // :241-248
 
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
     float4 q0 = vb[i0], q1 = vb[i1], q2 = vb[i2];
@@ -352,7 +354,7 @@ __device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int
             out |= (v[0][3] < +v[0][ax]) & (v[1][3] < +v[1][ax]) & (v[2][3] < +v[2][ax]);
             out |= (v[0][3] < -v[0][ax]) & (v[1][3] < -v[1][ax]) & (v[2][3] < -v[2][ax]);
         }
-        if (out) { p.bbox[so] = kEmptyBox; return 0; }
+        if (out) { empty_box(); return 0; }
     }
 
     bool inside = true;
@@ -362,12 +364,12 @@ __device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int
 
     if (inside) {                                                                    // :329-352
         SubTri st;
-        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist, stage);
-        else p.bbox[so] = kEmptyBox;
+        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist, stage, boxStage);
+        else empty_box();
     } else if (clipq) {
         clipq[atomicAdd(clipn, 1)] = i;
     } else {
-        return setup_clipped(p, n, i, v, t + 1, s_hist, stage, pool_slot);
+        return setup_clipped(p, n, i, v, t + 1, s_hist, stage, boxStage, pool_slot);
     }
     return 0;
 }
@@ -402,7 +404,9 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
     if (threadIdx.x == 0) s_clipn = 0;
     __syncthreads();
     const int i0 = bxi * 256;
-    setup_one(p, n, i0 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4, s_clipq, &s_clipn);
+    __shared__ uint32_t s_box[256];                          // AABBs of the block's slots: written out as one 1 KiB row
+    s_box[threadIdx.x] = kEmptyBox;                          // slots of queued (clipped) triangles are filled in pass 2b
+    setup_one(p, n, i0 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4, &s_box[threadIdx.x], s_clipq, &s_clipn);
     __syncthreads();
     // 2a: count the sub-triangles, reserve the block's pool slots with ONE global atomic (a returning
     // atomic per clipped triangle on the image's counter serialises: measured 0.5 ms on the stress scene)
@@ -414,14 +418,14 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
         const int ci = clip ? s_clipq[threadIdx.x] : 0;
         int poolOff = 0;
         if (clip) {
-            const int ns = setup_one(p, n, ci, s_hist, nullptr, nullptr, nullptr, -1);
+            const int ns = setup_one(p, n, ci, s_hist, nullptr, nullptr, nullptr, nullptr, -1);
             if (ns > 1) poolOff = atomicAdd(&s_poolNeed, ns - 1);
         }
         __syncthreads();
         if (threadIdx.x == 0 && s_poolNeed > 0) s_poolBase = atomicAdd(&p.poolCount[n], s_poolNeed);
         __syncthreads();
         // 2b: emit
-        if (clip) setup_one(p, n, ci, s_hist, s_rec + (ci - i0) * 4, nullptr, nullptr, s_poolBase + poolOff);
+        if (clip) setup_one(p, n, ci, s_hist, s_rec + (ci - i0) * 4, &s_box[ci - i0], nullptr, nullptr, s_poolBase + poolOff);
         __syncthreads();
     }
     {
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
             const int q = k * 64 + lane;                       // 16-byte chunk inside the wave's 4 KiB
             if (slot0 + (q >> 2) < cnt) dst[q] = src[q];
         }
+        if (slot0 + lane < cnt) p.bbox[(size_t)n * p.slots + slot0 + lane] = s_box[threadIdx.x];
     }
     // One global atomic per non-empty bin per block (instead of one per triangle).
     for (int b = threadIdx.x; b < nb; b += 256) {
