@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
     int vi0 = 0, vi1 = 0, vi2 = 0;
     if (valid) {
         vi0 = p.tri[triIdx * 3 + 0]; vi1 = p.tri[triIdx * 3 + 1]; vi2 = p.tri[triIdx * 3 + 2];
-        if (vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices)
+        if (!indices_ok(vi0, vi1, vi2, p.numVertices))
             return;                                         // corrupt indices: leave untouched (:54-58)
     }
     float* out = p.out + pidx * A;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
             continue;
         }
         const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
-        if (vi0 < 0 || vi0 >= p.numVertices || vi1 < 0 || vi1 >= p.numVertices || vi2 < 0 || vi2 >= p.numVertices)
+        if (!indices_ok(vi0, vi1, vi2, p.numVertices))
             continue;                                       // corrupt indices: leave untouched (:163-167)
         ok[r] = true;
         q[r].tri = triIdx; q[r].b0 = rr.x; q[r].b1 = rr.y;

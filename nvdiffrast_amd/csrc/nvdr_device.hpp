@@ -43,6 +43,14 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
 // Hardware f32 atomic add, no return value (global_atomic_add_f32).
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// All three vertex indices inside [0, V): one unsigned compare each, combined without short-circuit
+// evaluation (a chain of `<0 || >=V` tests compiles to nested divergent branches, each re-initialising
+// the values that are live across it).
+__device__ __forceinline__ bool indices_ok(int a, int b, int c, int V)
+{
+    return ((uint32_t)a < (uint32_t)V) & ((uint32_t)b < (uint32_t)V) & ((uint32_t)c < (uint32_t)V);
+}
+
 // XCD-aware decode of a 1-D grid into (block x, block y, image): blocks b, b+8, ... share an XCD
 // and walk a contiguous chunk of the (image-major) work list.
 __device__ __forceinline__ bool decode_block(int gx, int gy, int N, int& bx, int& by, int& pz)
