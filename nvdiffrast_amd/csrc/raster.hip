@@ -919,7 +919,7 @@ __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const flo
     int grad_all_ddb = 0;
     if (ENABLE_DB) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
     if ((((uint32_t)(grad_all_dy | grad_all_ddb)) << 1) == 0u) return false;          // all +-0 (:143-148)
-    if (!indices_ok(vi0, vi1, vi2, p.V)) return false;
+    if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) return false;   // (short-circuit form: measured faster here than indices_ok)
     r.tri = triIdx; r.vi0 = vi0; r.vi1 = vi1; r.vi2 = vi2;
 
     // Reverse-mode differentiation of the pixel shader (k_fine: barycentrics from the edge functions
