@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
 {
     // The parameter block is read where it lies, in the kernarg segment.  Handing the by-value struct to the
     // (deliberately not inlined) clipper by reference made the compiler copy it into scratch in every thread:
-    // 144 B x 655k threads = 94 MB of this kernel's 170 MB of HBM writes (PMC, profiles/r01e), and every
+    // 144 B x 655k threads = 94 MB of this kernel's 170 MB of HBM writes (PMC WRITE_SIZE), and every
     // later field access was a scratch load.
     (void)p_arg;
     const SetupParams& p = *(const SetupParams*)__builtin_amdgcn_kernarg_segment_ptr();
