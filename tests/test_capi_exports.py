@@ -132,3 +132,28 @@ def test_public_api_surface_matches_the_reference():
     assert inspect.signature(dr.texture).parameters["filter_mode"].default == "auto"
     assert inspect.signature(dr.texture).parameters["boundary_mode"].default == "wrap"
     assert inspect.signature(dr.antialias).parameters["pos_gradient_boost"].default == 1.0
+
+
+def test_scratch_clean_state_machine():
+    """RasterizeCRStateWrapper vouches for a clean control block only for the same buffer AND the same layout as
+    its previous SUCCESSFUL call (include/nvdr_hip.h, `scratch_clean`); everything else must report 0."""
+    import torch
+    from nvdiffrast_amd.torch._plugin import RasterizeCRStateWrapper
+    st = RasterizeCRStateWrapper(0)
+    cpu = torch.device("cpu")
+    a = (4, 100, 64, 64)
+    buf, clean = st.get_scratch(1024, cpu, a)
+    assert not clean                                   # first use
+    buf2, clean = st.get_scratch(1024, cpu, a)
+    assert not clean and buf2 is buf                   # previous call never reported success
+    st.mark_clean(a)
+    _, clean = st.get_scratch(1024, cpu, a)
+    assert clean                                       # same buffer, same layout, after a success
+    _, clean = st.get_scratch(1024, cpu, a)
+    assert not clean                                   # ... but the flag is consumed until the next success
+    st.mark_clean(a)
+    _, clean = st.get_scratch(512, cpu, (2, 100, 64, 64))
+    assert not clean                                   # other layout in the same buffer
+    st.mark_clean((2, 100, 64, 64))
+    buf3, clean = st.get_scratch(4096, cpu, (2, 100, 64, 64))
+    assert not clean and buf3 is not buf               # buffer had to grow: new memory
