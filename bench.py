@@ -167,7 +167,12 @@ def main():
             b = alg.get(name)
             kernels[name] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches / prof_steps,
                              "alg_bytes": b, "gbs": None if b is None else round(b / (avg_ms * 1e-3) / 1e9, 1)}
-        dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+        # Dominant kernel = largest share of the step.  k_fine and k_interp_grad take the same time to within
+        # run-to-run noise, so kernels within 5 % of the longest are treated as tied and the tie goes to the one
+        # that moves the most algorithmic bytes (every kernel's own numbers are in `kernels` either way).
+        share = {k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"] for k in kernels}
+        top = max(share.values())
+        dominant = max((k for k in share if share[k] >= 0.95 * top), key=lambda k: (kernels[k]["alg_bytes"] or 0, share[k]))
         dk = kernels[dominant]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes/launch, if collected
