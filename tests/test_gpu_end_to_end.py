@@ -4,7 +4,9 @@ per-op parity would miss (wrong sign, a gradient routed to the wrong tensor, a s
 import importlib.util
 import os
 
+import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -91,3 +93,28 @@ def test_pose_is_recovered_from_a_single_image(dr):
     assert r["err_deg_initial"] > 20, r
     assert r["err_deg_after_search"] < 25, r
     assert r["err_deg_final"] < 0.2 and r["err_deg_final"] <= r["err_deg_after_search"], r
+
+
+def test_pipeline_matches_committed_fixture(dr):
+    """The whole op chain (rasterize -> interpolate with differentials -> trilinear texture -> antialias, forward
+    and backward through autograd) against the committed vectors of tests/golden/pipeline_small.npz."""
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "pipeline_small.npz"))
+    dev = torch.device("cuda", 0)
+    t = lambda k: torch.from_numpy(fx["in_" + k]).to(dev)
+    pos = t("pos").requires_grad_(True); uvattr = t("uv").requires_grad_(True); tex = t("tex").requires_grad_(True)
+    tri = t("tri")
+    H, W = fx["out_rast"].shape[1:3]
+    ctx = dr.RasterizeCudaContext(device=dev)
+    rast, rast_db = dr.rasterize(ctx, pos, tri, (H, W))
+    uv, uv_da = dr.interpolate(uvattr, rast, tri, rast_db=rast_db, diff_attrs="all")
+    col = dr.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear")
+    out = dr.antialias(col, rast, pos, tri)
+    torch.autograd.backward(out, t("g_out"))
+    got = dict(rast=rast, rast_db=rast_db, uv=uv, uv_da=uv_da, col=col, out=out,
+               g_tex=tex.grad, g_uvattr=uvattr.grad, g_pos=pos.grad)
+    assert np.array_equal(rast[..., 3].detach().cpu().numpy(), fx["out_rast"][..., 3])          # ids: bit exact
+    for k, v in got.items():
+        ref = fx["out_" + k]
+        err = np.abs(v.detach().cpu().numpy() - ref).max()
+        tol = 1e-5 * max(1.0, float(np.abs(ref).max())) * (4.0 if k.startswith("g_") else 1.0)   # f32 sums of O(100) terms
+        assert err <= tol, (k, err, tol)

@@ -368,3 +368,22 @@ def test_cube_mip_level_gradient_wrt_direction(oracle):
         um = v.copy(); um[..., k] -= eps
         fd = (f(up) - f(um)) / (2 * eps)
         assert np.abs(fd - g["uv"][..., k]).max() < 2e-2 * max(1.0, np.abs(fd).max())
+
+
+def test_pipeline_fixture_is_reproduced(oracle):
+    """tests/golden/pipeline_small.npz (made by tests/golden/make_pipeline_fixture.py) pins the oracle's output
+    on a whole forward+backward op chain: any change to the restatement shows up here."""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_pipeline_fixture", os.path.join(here, "make_pipeline_fixture.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    fx = np.load(os.path.join(here, "pipeline_small.npz"))
+    i = gen.inputs()
+    for k, v in i.items():
+        assert np.array_equal(fx["in_" + k], v), k                      # the generator is deterministic
+    o = gen.run_oracle(i)
+    assert np.array_equal(o["rast"][..., 3], fx["out_rast"][..., 3])     # triangle ids: exact
+    for k, v in o.items():
+        ref = fx["out_" + k]
+        assert np.abs(v - ref).max() <= 1e-6 * max(1.0, float(np.abs(ref).max())), k
