@@ -11,8 +11,11 @@
 //                      buffer with ONE returning atomic per 2048 pixels (the shared counter is the
 //                      only contended word; the reference: one atomic per 32x8 CTA, :197-209).
 //  k_aa_analysis       one lane per work item, grid-stride (item count lives on the device):
-//                      silhouette test, edge crossing, blend with hardware f32 atomics (:236-379).
-//  k_aa_grad           one lane per work item with alpha != 0 (:406-554).
+//                      silhouette test and edge crossing (:236-379); the blends of a workgroup's 256
+//                      items are staged in LDS and added with the channels of one pixel on
+//                      consecutive lanes (one memory transaction per pixel instead of one per channel).
+//  k_aa_grad           one lane per work item with alpha != 0 (:406-554); colour and position
+//                      updates are emitted transposed in the same way.
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
 

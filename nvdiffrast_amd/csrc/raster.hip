@@ -9,24 +9,31 @@
 //  k_setup   one lane per triangle: snap / cull / clip / depth-plane setup.  Emits a 64 B
 //            record per surviving (sub)triangle: three edge functions in "pixel form"
 //            E(X,Y) = C + X*A + Y*B (fill rule folded into C), the depth plane, the id
-//            and a packed tile AABB.  Clipped triangles take extra slots from a per-image
-//            pool sized for the worst case (7 sub-triangles), so nothing can overflow and
-//            the host never synchronises (the reference retries after a D2H copy,
-//            RasterImpl.cpp:174-231,367).
-//  k_fine    one workgroup (8 waves) per 64x64-pixel bin, one wave per row of eight 8x8
-//            tiles, ONE LANE PER PIXEL.  Waves scan the image's packed AABBs, compact the
-//            bin's triangles into an LDS list with ballot/mbcnt prefix sums, then each wave
-//            walks the list 64 triangles at a time: a ballot over "AABB touches tile"
-//            yields the per-tile hit mask, and every hit is evaluated by all 64 pixels at
-//            once (3 edge mads + 1 depth mad per lane).  Visibility is a per-lane running
-//            minimum of the key (depth << 32 | ~id): minimum depth wins, ties go to the
-//            highest triangle id, which is exactly what the reference's in-order LEQUAL
-//            ROP produces (FineRaster.inl:152-172,349-361) but needs no ordering, no LDS
-//            atomics and no colour/depth surface.  The winning id goes straight into the
-//            pixel shader (rasterize.cu:15-114) in the same kernel, so the id/depth
-//            surfaces never touch HBM (the depth surface is stored only for depth peeling).
-//  k_grad    rasterize.cu:119-277; gradients are accumulated per vertex in an LDS fixed-point hash
-//            table per 64x64 pixel block and flushed with one hardware atomic per (vertex, component).
+//            and a packed tile AABB; records and AABBs are staged in LDS and leave as whole
+//            rows.  Clipped triangles are queued and set up densely in a second pass; their
+//            sub-triangles take slots from a per-image pool sized for the worst case (7 per
+//            triangle), so nothing can overflow and the host never synchronises (the
+//            reference retries after a D2H copy, RasterImpl.cpp:174-231,367).  Per-bin
+//            triangle counts and slot ranges are accumulated in an LDS histogram.
+//  k_order   heavy-first work order of the (image, bin) items inside each XCD's chunk; last
+//            reader of k_setup's counters, which it leaves zeroed for the next call.
+//  k_fine    one workgroup (8 waves) per 64x64-pixel bin.  (1) The waves scan the bin's range
+//            of packed AABBs and compact the triangles that touch the bin into an LDS list
+//            (ballot/mbcnt prefix sums).  (2) The list's (triangle, 8x8 tile) pairs are numbered
+//            by a prefix sum and dealt to the waves 64 at a time, ONE LANE PER PAIR: the lane
+//            walks its triangle's three edge functions over the tile's 64 pixel centres with
+//            integer adds into a 64-bit coverage mask, then pops the set bits and merges
+//            depth << 32 | ~id into the tile's per-pixel keys with an LDS 64-bit atomic min:
+//            minimum depth wins, ties go to the highest triangle id, which is exactly what
+//            the reference's in-order LEQUAL ROP produces (FineRaster.inl:152-172,349-361)
+//            without needing any ordering.  (3) One lane per pixel: the winning id goes
+//            straight into the pixel shader (rasterize.cu:15-114) in the same kernel, so the
+//            id/depth surfaces never touch HBM (the depth surface is stored only for depth
+//            peeling).
+//  k_raster_grad  rasterize.cu:119-277; per-pixel gradients (a reverse-mode tape of the pixel
+//            shader) are summed over triangle runs, accumulated per vertex in an LDS fixed-point
+//            hash table per 64x16-pixel block and flushed with one hardware atomic per
+//            (vertex, component).
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
 

@@ -8,9 +8,11 @@
 //                a wave land in a compact texture footprint (L1/L2 hits); uv / uv_da / out are
 //                read and written as whole float2 / float4 per lane.  Tiles are handed to the
 //                XCDs in contiguous chunks so neighbouring tiles share an L2.
-//  k_tex_grad    same mapping; texel weights are accumulated in an LDS patch table (64-bit fixed
-//                point) and flushed with line-coalesced hardware f32 atomics; uv / uv_da / bias
-//                gradients are written per pixel (texture_kernel.cu:905-1140).
+//  k_tex_grad    same mapping; texel weights are accumulated in an LDS table of 8x2-texel patches
+//                (32-bit fixed point, 32-bit keys), pixels with identical footprints are merged in
+//                registers first, and only the claimed patches are flushed, with line-coalesced
+//                hardware f32 atomics; uv / uv_da / bias gradients are written per pixel
+//                (texture_kernel.cu:905-1140).
 //  k_mip_grad    one lane per base texel pulls its ancestors' gradients (:843-895).
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
