@@ -127,12 +127,13 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
     const int A = A_CT > 0 ? A_CT : p.numAttr;
     unsigned long long* s_vals = (unsigned long long*)s_mem;
     uint32_t* s_keys = (uint32_t*)(s_mem + (size_t)slots * A * 8);
-    uint32_t* s_max = s_keys + slots;
+    uint32_t* s_max = s_keys + slots;                       // [0] block max, [1] number of used slots
+    uint16_t* s_list = (uint16_t*)(s_max + 4);              // [slots] used slots (flush)
     int bx, by, pz;
     if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
     VertexTable tab{s_keys, s_vals, slots, A};
     tab.clear(threadIdx.x, kIpThreads);
-    if (threadIdx.x == 0) *s_max = 0u;
+    if (threadIdx.x == 0) { s_max[0] = 0u; s_max[1] = 0u; }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,14 +290,12 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
 
     // Flush: one atomic per (vertex, attribute) this block touched.
     __syncthreads();
-    const int n = slots * A;
+    const int n = tab.compact(s_list, &s_max[1], threadIdx.x, kIpThreads) * A;
     for (int i = threadIdx.x; i < n; i += kIpThreads) {
-        const int slot = i / A;
-        const uint32_t key = s_keys[slot];
-        if (key) {
-            const unsigned long long t = s_vals[i];
-            if (t) atomic_add_f32(gattr + (size_t)(key - 1u) * A + (i - slot * A), fs.to_float(t));
-        }
+        const int u = i / A, c = i - u * A;
+        const int slot = s_list[u];
+        const unsigned long long t = s_vals[slot * A + c];
+        if (t) atomic_add_f32(gattr + (size_t)(s_keys[slot] - 1u) * A + c, fs.to_float(t));
     }
 }
 
@@ -399,8 +398,8 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
     dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kIpThreads);
     // LDS vertex table: as many power-of-two slots as fit in 20 KiB (8 workgroups per CU), at most 512.
     int slots = 512;
-    while (slots > 32 && (size_t)slots * (8 * A + 4) > 20 * 1024) slots >>= 1;
-    const size_t lds = (size_t)slots * (8 * A + 4) + 16;
+    while (slots > 32 && (size_t)slots * (8 * A + 6) + 16 > 20 * 1024) slots >>= 1;
+    const size_t lds = (size_t)slots * (8 * A + 6) + 16;    // sums + key + used-list entry per slot
     NVDR_REQUIRE(lds <= 64 * 1024, "interpolate_grad: too many attributes (%d) for the LDS accumulator", A);
     const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);
     const bool vec2 = (A == 2) && !((uintptr_t)attr & 7) && !((uintptr_t)dy & 7);

@@ -295,6 +295,16 @@ struct VertexTable {
     __device__ __forceinline__ void add(int slot, int comp, unsigned long long v) const {
         atomicAdd(&vals[slot * stride + comp], v);
     }
+    // Lists the claimed slots in `list` and returns their number (`counter` must be zero on entry; every
+    // thread of the workgroup calls this, it contains a barrier).  The flush then walks only what was used:
+    // a 64x16-pixel block touches a quarter of the table, a scan of all of it was a tenth of the
+    // backward kernels' instructions.
+    __device__ __forceinline__ int compact(uint16_t* list, uint32_t* counter, int tid, int nthreads) const {
+        for (int i = tid; i < slots; i += nthreads)
+            if (keys[i] != 0u) list[atomicAdd(counter, 1u)] = (uint16_t)i;
+        __syncthreads();
+        return (int)*counter;
+    }
 };
 
 }  // namespace nvdr

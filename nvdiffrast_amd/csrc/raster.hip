@@ -1008,12 +1008,13 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 {
     __shared__ uint32_t s_keys[kGradSlots];
     __shared__ unsigned long long s_vals[kGradSlots * 3];
-    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_max, s_used;
+    __shared__ uint16_t s_list[kGradSlots];
     int bx, by, pz;
     if (!decode_block(gx, gy, p.N, bx, by, pz)) return;
     VertexTable tab{s_keys, s_vals, kGradSlots, 3};
     tab.clear(threadIdx.x, kGradThreads);
-    if (threadIdx.x == 0) s_max = 0u;
+    if (threadIdx.x == 0) { s_max = 0u; s_used = 0u; }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1086,13 +1087,12 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 
     // Flush: one atomic per (vertex, component) this block touched.
     __syncthreads();
-    for (int i = threadIdx.x; i < kGradSlots * 3; i += kGradThreads) {
-        const int slot = i / 3, c = i - slot * 3;
-        const uint32_t key = s_keys[slot];
-        if (key) {
-            const unsigned long long t = s_vals[i];
-            if (t) atomic_add_f32(gout + (size_t)(key - 1u) * 4 + (c == 2 ? 3 : c), fs.to_float(t));
-        }
+    const int nflush = tab.compact(s_list, &s_used, threadIdx.x, kGradThreads) * 3;
+    for (int i = threadIdx.x; i < nflush; i += kGradThreads) {
+        const int u = i / 3, c = i - u * 3;
+        const int slot = s_list[u];
+        const unsigned long long t = s_vals[slot * 3 + c];
+        if (t) atomic_add_f32(gout + (size_t)(s_keys[slot] - 1u) * 4 + (c == 2 ? 3 : c), fs.to_float(t));
     }
 }
 
