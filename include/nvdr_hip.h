@@ -36,6 +36,21 @@ enum {
 const char* nvdr_last_error(void);
 int         nvdr_abi_version(void);
 
+/* Process-wide options.  Defaults reproduce the reference; nvdr_set_option returns NVDR_ERR_ARG for an unknown id.
+ *  NVDR_OPT_LOG_LEVEL        c10 log severity threshold, the value behind get_log_level / set_log_level
+ *                            (torch_bindings.cpp:50-51): messages of severity >= level go to stderr
+ *                            (0 INFO, 1 WARNING (default), 2 ERROR, 3 FATAL).  The one message on this path is the
+ *                            rasterizer's INFO "Internal buffers grown to N MB" (RasterImpl.cpp:195), which the
+ *                            host glue emits when it regrows the scratch it owns.
+ *  NVDR_OPT_CUBE_CORNER_FIX  0 (default): cube-map corner texels exactly as the reference samples them, including
+ *                            its loss of the corner flag for texture slices >= 1 (texture_kernel.cu:85-88,431-432);
+ *                            1: the missing corner texel is the average of the other three for every slice. */
+enum { NVDR_OPT_LOG_LEVEL = 0, NVDR_OPT_CUBE_CORNER_FIX = 1, NVDR_OPT_COUNT = 2 };
+int nvdr_set_option(int option, int value);
+int nvdr_get_option(int option);
+/* Writes `msg` to stderr as "[nvdr] msg" when `severity` >= NVDR_OPT_LOG_LEVEL; returns 1 if it was written. */
+int nvdr_log(int severity, const char* msg);
+
 /* Per-kernel timing hooks used by bench.py (hipEvent pairs recorded on the launch
  * stream around every kernel while enabled).  nvdr_profile_read fills up to `cap`
  * entries (name pointers stay valid for the library's lifetime) and returns the count;

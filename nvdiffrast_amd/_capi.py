@@ -17,11 +17,15 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
-ABI_VERSION = 2            # include/nvdr_hip.h; 2: nvdr_rasterize_fwd takes scratch_clean
+ABI_VERSION = 3            # include/nvdr_hip.h; 2: nvdr_rasterize_fwd takes scratch_clean; 3: options + log
+OPT_LOG_LEVEL, OPT_CUBE_CORNER_FIX = 0, 1
 
 SIGNATURES = {
     "nvdr_last_error": (ctypes.c_char_p, []),
     "nvdr_abi_version": (c_int, []),
+    "nvdr_set_option": (c_int, [c_int, c_int]),
+    "nvdr_get_option": (c_int, [c_int]),
+    "nvdr_log": (c_int, [c_int, ctypes.c_char_p]),
     "nvdr_profile_enable": (None, [c_int]),
     "nvdr_profile_reset": (None, []),
     "nvdr_profile_read": (c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), c_int]),

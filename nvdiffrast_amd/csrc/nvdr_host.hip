@@ -18,6 +18,9 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_options[NVDR_OPT_COUNT] = {1 /* WARNING */, 0};
+int get_option(int option) { return (option >= 0 && option < NVDR_OPT_COUNT) ? g_options[option] : 0; }
+
 struct Timed { const char* name; hipEvent_t a, b; };
 static bool g_prof = false;
 static std::mutex g_mu;
@@ -58,7 +61,19 @@ void profile_end(hipStream_t s) {
 extern "C" {
 
 const char* nvdr_last_error(void) { return nvdr::g_err; }
-int nvdr_abi_version(void) { return 2; }
+int nvdr_abi_version(void) { return 3; }
+
+int nvdr_set_option(int option, int value) {
+    if (option < 0 || option >= NVDR_OPT_COUNT) { nvdr::set_error("nvdr_set_option: unknown option %d", option); return NVDR_ERR_ARG; }
+    nvdr::g_options[option] = value;
+    return NVDR_OK;
+}
+int nvdr_get_option(int option) { return nvdr::get_option(option); }
+int nvdr_log(int severity, const char* msg) {
+    if (severity < nvdr::g_options[NVDR_OPT_LOG_LEVEL]) return 0;
+    fprintf(stderr, "[nvdr] %s\n", msg ? msg : "");
+    return 1;
+}
 
 void nvdr_profile_enable(int on) { nvdr::g_prof = on != 0; }
 void nvdr_debug_buffer(void* p) { nvdr::g_dbgbuf = (unsigned long long*)p; }

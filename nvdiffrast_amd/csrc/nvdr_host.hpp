@@ -12,6 +12,9 @@ namespace nvdr {
 
 void set_error(const char* fmt, ...);
 
+// Process-wide options (nvdr_set_option); defaults reproduce the reference.
+int get_option(int option);
+
 // Optional per-kernel hipEvent timing (bench.py only).
 bool profile_on();
 void profile_begin(const char* name, hipStream_t s);

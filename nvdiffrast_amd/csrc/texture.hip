@@ -30,6 +30,7 @@ struct TexParams {
     float* out; float* gradUV; float* gradUVDA; float* gradBias;
     int boundary, channels, imgW, imgH, n, texW, texH, texDepth, levelMax;
     int tilesX, tilesY, dbg;
+    int cornerFix;                  // NVDR_OPT_CUBE_CORNER_FIX: keep the cube-corner flag for texture slices >= 1
 };
 
 __device__ __forceinline__ int level_dim(int d, int level) { int v = d >> level; return v > 1 ? v : 1; }
@@ -107,6 +108,16 @@ __device__ __forceinline__ bool finite4(float4 a) { return isfinite(a.x) && isfi
 // reference implements, :87-110); the gradient helpers are the derivatives of that map and texels
 // beyond a face edge are folded onto the neighbouring face with integer geometry.
 
+// 1/x rounded towards zero for x >= 0, as the reference's __frcp_rz (:110,136,163,206,264): the correctly
+// rounded quotient, stepped one ulp down when it lies above the exact value (sign of the exact residual
+// r*x - 1 from one fma).  +inf from a denormal x steps down to FLT_MAX, as round-towards-zero overflow does.
+__device__ __forceinline__ float rcp_rz(float x)
+{
+    float r = 1.f / x;
+    if (__fmaf_rn(r, x, -1.f) > 0.f) r = __uint_as_float(__float_as_uint(r) - 1u);
+    return r;
+}
+
 struct CubeFace { int ma, msgn, sa, ss, ta, ts; };
 __device__ __forceinline__ CubeFace cube_face(int f)
 {
@@ -141,7 +152,7 @@ __device__ __forceinline__ int cube_index(float3 v, float& s, float& t)
 #pragma clang fp contract(off)
     const int f = cube_face_of(v);
     const CubeFace F = cube_face(f);
-    const float m = (1.f / fabsf(comp3(v, F.ma))) * .5f;
+    const float m = rcp_rz(fabsf(comp3(v, F.ma))) * .5f;
     const float x = __fmaf_rn(comp3(v, F.sa), (float)F.ss * m, .5f);
     const float y = __fmaf_rn(comp3(v, F.ta), (float)F.ts * m, .5f);
     if (!isfinite(x) || !isfinite(y)) return -1;
@@ -196,6 +207,13 @@ __device__ __forceinline__ Quad tex_index_linear_cube(const TexParams& p, float3
     for (int k = 0; k < 4; k++) {
         int cx, cy;
         if (cube_texel(f, iu0 + (k & 1), iv0 + (k >> 1), w, cx, cy)) { q.tx[k] = cx; q.ty[k] = cy; q.tc[k] = base + cx + w * cy; }
+        else if (tz > 0 && !p.cornerFix) {
+            // The reference marks the missing corner texel with face -1, x = y = 0, i.e. index -w*w (:85-88), and then
+            // adds 6*tz*w*w to all four indices (:431-432): for slices >= 1 the mark becomes texel (0,0) of face 5 of the
+            // PREVIOUS slice, sampled with its bilinear weight and without the corner average.  Reproduced by default;
+            // tx = -1 keeps the tap out of the per-slice LDS patch table of the gradient kernel (direct atomic instead).
+            q.tc[k] = base - w * w; q.tx[k] = -1; q.ty[k] = 0;
+        }
         else q.corner = true;
     }
     return q;
@@ -207,7 +225,7 @@ __device__ __forceinline__ float3 cube_grad(float3 v, float gu, float gv)
 #pragma clang fp contract(off)
     const CubeFace F = cube_face(cube_face_of(v));
     const float c = comp3(v, F.ma);
-    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float m = rcp_rz(fabsf(c)), h = m * .5f;
     const float su = (float)F.ss * gu, sv = (float)F.ts * gv;
     const float sg = (c < 0.f) ? 1.f : -1.f;
     float3 g = make_float3(0.f, 0.f, 0.f);
@@ -224,7 +242,7 @@ __device__ __forceinline__ float4 cube_grad_st(float3 v, float3 dX, float3 dY)
 #pragma clang fp contract(off)
     const CubeFace F = cube_face(cube_face_of(v));
     const float c = comp3(v, F.ma);
-    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float m = rcp_rz(fabsf(c)), h = m * .5f;
     const float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
     const float ss = (float)F.ss, ts = (float)F.ts, a = comp3(v, F.sa), b = comp3(v, F.ta);
     const float4 r = make_float4(ss * (h * comp3(dX, F.sa) - k * a * comp3(dX, F.ma)), ss * (h * comp3(dY, F.sa) - k * a * comp3(dY, F.ma)),
@@ -238,7 +256,7 @@ __device__ __forceinline__ float3 cube_grad2_dot(float3 v, float3 dX, float3 dY,
 #pragma clang fp contract(off)
     const CubeFace F = cube_face(cube_face_of(v));
     const float c = comp3(v, F.ma);
-    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float m = rcp_rz(fabsf(c)), h = m * .5f;
     const float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
     const float k2 = 2.f * k / c;
     const float ss = (float)F.ss, ts = (float)F.ts, a = comp3(v, F.sa), b = comp3(v, F.ta);
@@ -261,7 +279,7 @@ __device__ __forceinline__ void cube_grad4(float3 v, float4 dw, float3& g0, floa
 #pragma clang fp contract(off)
     const CubeFace F = cube_face(cube_face_of(v));
     const float c = comp3(v, F.ma);
-    const float m = 1.f / fabsf(c), h = m * .5f;
+    const float m = rcp_rz(fabsf(c)), h = m * .5f;
     const float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
     const float ss = (float)F.ss, ts = (float)F.ts, a = comp3(v, F.sa), b = comp3(v, F.ta);
     g0 = make_float3(0.f, 0.f, 0.f); g1 = g0;
@@ -618,7 +636,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         if (direct || (p.dbg & 1024)) return;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (q.tc[k] < 0) continue;
+            if (q.tc[k] < 0 || q.tx[k] < 0) continue;
             bool reused = false;
 #pragma unroll
             for (int j = 0; j < k; j++) {
@@ -935,6 +953,7 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
     p.tilesX = (W + 15) / 16; p.tilesY = (H + 15) / 16;
     NVDR_REQUIRE((long long)p.tilesX * p.tilesY * N < (1ll << 30), "%s: too many pixel blocks", who);
     p.dbg = debug_flags();
+    p.cornerFix = get_option(NVDR_OPT_CUBE_CORNER_FIX);
     return NVDR_OK;
 }
 

@@ -15,16 +15,30 @@ import torch
 
 from .. import _capi
 
-_log_level = 1  # torch_bindings.cpp:50-51 forwards to FLAGS_caffe2_log_level (default 1 per ops.py:34)
-
+# torch_bindings.cpp:50-51 forward to c10's FLAGS_caffe2_log_level (0 INFO, 1 WARNING = default, 2 ERROR, 3 FATAL);
+# here the level lives in the native library (NVDR_OPT_LOG_LEVEL) and gates nvdr_log().
 
 def get_log_level():
-    return _log_level
+    return int(_capi.load().nvdr_get_option(_capi.OPT_LOG_LEVEL))
 
 
 def set_log_level(level):
-    global _log_level
-    _log_level = int(level)
+    _capi.check(_capi.load().nvdr_set_option(_capi.OPT_LOG_LEVEL, int(level)), "set_log_level")
+
+
+def set_cube_corner_fix(enable):
+    """Not in the reference.  False (default): cube-map corner texels are sampled exactly as the reference does,
+    including its loss of the corner flag for texture slices >= 1 (texture_kernel.cu:85-88,431-432).  True: the
+    texel missing at a cube corner is the average of the other three for every slice."""
+    _capi.check(_capi.load().nvdr_set_option(_capi.OPT_CUBE_CORNER_FIX, int(bool(enable))), "set_cube_corner_fix")
+
+
+def _is_capturing(device):
+    return torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
+def _log_info(msg):
+    _capi.load().nvdr_log(0, msg.encode())
 
 
 # ----------------------------------------------------------------------------- checks
@@ -98,16 +112,36 @@ class RasterizeCRStateWrapper:
         self.cuda_device_idx = int(cuda_device_idx)
         self.scratch = None
         self.clean_layout = None
+        self.captured = False    # some call of this context was recorded into a hipGraph
+        self.retired = []        # scratch buffers that recorded graphs still point to
+        self.reported_bytes = 0
         self.depth = None        # current depth surface  [N,Hp,Wp] int32 (u32 bits)
         self.peel = None         # previous layer's depth surface
 
     def get_scratch(self, nbytes, device, layout):
         """Returns (buffer, clean): `clean` tells the library that the buffer's control block is as this
-        context's previous successful call with the same layout left it (include/nvdr_hip.h)."""
+        context's previous successful call with the same layout left it (include/nvdr_hip.h).
+
+        hipGraph capture freezes both the buffer address and the flag into the recorded launches, while the
+        graph may be replayed after calls with other layouts have used the buffer.  So a call recorded during
+        capture never claims a clean buffer (its memset becomes part of the graph and every replay is
+        self-contained), a context that has been captured never claims one again in eager mode either
+        (a replay may have run in between), and a buffer that a graph may point to is kept alive when the
+        context outgrows it."""
+        capturing = _is_capturing(device)
         if self.scratch is None or self.scratch.numel() < nbytes or self.scratch.device != device:
+            if self.captured and self.scratch is not None:
+                self.retired.append(self.scratch)
             self.scratch = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
             self.clean_layout = None
-        clean = self.clean_layout == layout
+            if nbytes > self.reported_bytes:
+                # RasterImpl.cpp:189-197: report growth at 10 MB granularity, INFO severity
+                mb = ((((int(nbytes) - 1) >> 20) + 1 + 9) // 10) * 10
+                _log_info("Internal buffers grown to %d MB" % mb)
+                self.reported_bytes = mb << 20
+        if capturing:
+            self.captured = True
+        clean = (self.clean_layout == layout) and not self.captured
         self.clean_layout = None                  # re-armed by mark_clean() once the call has succeeded
         return self.scratch, clean
 

@@ -182,6 +182,11 @@ _BOUNDARY = {"cube": 0, "wrap": 1, "clamp": 2, "zero": 3}
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
 
+def set_cube_corner_fix(on):
+    """False (default) = the reference's cube-corner behaviour, lost corner flag for slices >= 1 included."""
+    lib().nvdro_set_cube_corner_fix(int(bool(on)))
+
+
 def _tex_dims(tex_shape):
     """(n, h, w, c, cube) of a [n,h,w,c] texture or a [n,6,s,s,c] cube map."""
     if len(tex_shape) == 5:

@@ -97,6 +97,10 @@ int nvdro_texture_build_mip(const float* tex, int tex_n, int tex_h, int tex_w, i
  * boundary: 0 cube (tex [tex_n,6,S,S,C], uv 3 and uv_da 6 components per pixel), 1 wrap, 2 clamp,
  * 3 zero.  uv_da / mip_level_bias may be NULL.
  * mip_ptrs: L pointers (levels 1..L), each [tex_n,(6,)h,w,C]; may be NULL if L == 0. */
+/* 0 (default): cube corner texels as the reference treats them, including the lost corner flag for texture
+ * slices >= 1 (texture_kernel.cu:431-432); 1: the flag is kept for every slice (opt-in fix). */
+void nvdro_set_cube_corner_fix(int on);
+
 int nvdro_texture_fwd(const float* tex, const float* const* mip_ptrs, int L,
                       const float* uv, const float* uv_da, const float* mip_level_bias,
                       int tex_n, int tex_h, int tex_w, int C,

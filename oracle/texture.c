@@ -5,7 +5,9 @@
  * :644-699 (mip build), :709-800 (forward), :843-895 (mip gradient pull), :905-1140 (backward)
  * and the glue semantics of csrc/torch/torch_texture.cpp.
  *
- * Parity unpinned: the reference holds no golden vectors for this op.  Gradient sums are
+ * Pinned to the reference itself: tests run every call also through oracle/_ref (the reference's own
+ * texture_kernel.cu / texture.cpp / torch_texture.cpp compiled for the host) and require agreement
+ * (oracle/pinned.py, tests/test_ref_pins_oracle.py).  Gradient sums are
  * accumulated in f64 in pixel order.  The one fused multiply-add written out below
  * (texel-space coordinate u*w - 0.5) is where nvcc contracts by default; the HIP kernels use the
  * same explicit fma so both sides agree to the last bit on texel weights.
@@ -13,8 +15,12 @@
  * reference's bit tables: the face table below is the OpenGL convention the reference implements
  * (s = sa*ss/(2|c|) + 1/2, t = ta*ts/(2|c|) + 1/2), its gradient functions are the derivatives of that
  * map, and texels beyond a face edge are folded onto the neighbouring face with integer geometry.
- * One deliberate difference: the texel missing at a cube corner is always flagged; the reference
- * loses the flag for slices tz >= 1 (it adds 6*tz*w*h to the negative index, :431-432).
+ * The texel missing at a cube corner: the reference flags it with index -1 and then adds 6*tz*w*h to all four
+ * indices (:431-432).  wrapCubeMap gives the missing texel face -1 and x = y = 0, i.e. index -w*w (:85-88), so for
+ * texture slices tz >= 1 the "flag" becomes the valid index 6*tz*w*w - w*w (texel (0,0) of face 5 of the previous
+ * slice), which is then sampled with its bilinear weight, and the corner average is lost.  That is reproduced here by default;
+ * nvdro_set_cube_corner_fix(1) keeps the flag for every slice instead (opt-in, not reference behaviour).
+ * Reciprocals of the major axis are rounded towards zero like the reference's __frcp_rz (:110,136,163,206,264).
  */
 #include "nvdr_oracle.h"
 
@@ -25,6 +31,21 @@
 enum { F_NEAREST = 0, F_LINEAR = 1, F_LMN = 2, F_LML = 3 };
 enum { B_CUBE = 0, B_WRAP = 1, B_CLAMP = 2, B_ZERO = 3 };
 #define MAX_LEVELS 17
+
+static int g_cube_corner_fix = 0;
+void nvdro_set_cube_corner_fix(int on) { g_cube_corner_fix = on ? 1 : 0; }
+
+/* __frcp_rz: 1/x rounded towards zero.  The double quotient is exact to 53 bits and a float reciprocal that
+ * is not exactly representable lies further than that from any float, so truncating the double is exact. */
+static float frcp_rz(float x)
+{
+    double d = 1.0 / (double)x;
+    float f = (float)d;
+    if (isnan(f)) return f;
+    if (isinf(f)) return isinf(d) ? f : copysignf(3.402823466e+38f, f);
+    if (fabs((double)f) > fabs(d)) f = nextafterf(f, 0.f);
+    return f;
+}
 
 static int level_dim(int d, int level) { int v = d >> level; return v > 1 ? v : 1; }   /* texture.h mipLevelSize */
 
@@ -174,7 +195,7 @@ static int cube_index(const float v[3], float* s, float* t)
 {
     int f = cube_face_of(v);
     const CubeFace* F = &kFace[f];
-    float m = (1.f / fabsf(v[F->ma])) * .5f;
+    float m = frcp_rz(fabsf(v[F->ma])) * .5f;
     float x = fmaf(v[F->sa], (float)F->ss * m, .5f);
     float y = fmaf(v[F->ta], (float)F->ts * m, .5f);
     if (!isfinite(x) || !isfinite(y)) return -1;
@@ -224,8 +245,9 @@ static int index_linear_cube(const TexCfg* t, const float v3[3], int tz, int lev
     int xs[4] = {iu0, iu1, iu0, iu1}, ys[4] = {iv0, iv0, iv1, iv1};
     for (int k = 0; k < 4; k++) {
         int64_t c = cube_texel(f, xs[k], ys[k], w);
-        tc[k] = c < 0 ? -1 : base + c;
-        if (c < 0) *corner = 1;
+        if (c >= 0) tc[k] = base + c;
+        else if (tz > 0 && !g_cube_corner_fix) tc[k] = base - (int64_t)w * w;   /* texture_kernel.cu:85-88,431-432: flag lost */
+        else { tc[k] = -1; *corner = 1; }
     }
     return 1;
 }
@@ -235,7 +257,7 @@ static void cube_grad(const float v[3], float gu, float gv, float g[3])
 {
     const CubeFace* F = &kFace[cube_face_of(v)];
     float c = v[F->ma];
-    float m = 1.f / fabsf(c), h = m * .5f;
+    float m = frcp_rz(fabsf(c)), h = m * .5f;
     float su = (float)F->ss * gu, sv = (float)F->ts * gv;
     float sg = (c < 0.f) ? 1.f : -1.f;                                     /* -sign(c) */
     g[F->sa] = su * h;
@@ -249,7 +271,7 @@ static void cube_grad_st(const float v[3], const float dX[3], const float dY[3],
 {
     const CubeFace* F = &kFace[cube_face_of(v)];
     float c = v[F->ma];
-    float m = 1.f / fabsf(c), h = m * .5f;
+    float m = frcp_rz(fabsf(c)), h = m * .5f;
     float k = ((c < 0.f) ? -1.f : 1.f) * m * h;                            /* sign(c) / (2 c^2) */
     float ss = (float)F->ss, ts = (float)F->ts, a = v[F->sa], b = v[F->ta];
     r[0] = ss * (h * dX[F->sa] - k * a * dX[F->ma]);
@@ -264,7 +286,7 @@ static void cube_grad2(const float v[3], const float dX[3], const float dY[3], f
 {
     const CubeFace* F = &kFace[cube_face_of(v)];
     float c = v[F->ma];
-    float m = 1.f / fabsf(c), h = m * .5f;
+    float m = frcp_rz(fabsf(c)), h = m * .5f;
     float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
     float k2 = 2.f * k / c;                                                /* -dk/dc */
     float ss = (float)F->ss, ts = (float)F->ts, a = v[F->sa], b = v[F->ta];
@@ -284,7 +306,7 @@ static void cube_grad4(const float v[3], const float dw[4], float g0[3], float g
 {
     const CubeFace* F = &kFace[cube_face_of(v)];
     float c = v[F->ma];
-    float m = 1.f / fabsf(c), h = m * .5f;
+    float m = frcp_rz(fabsf(c)), h = m * .5f;
     float k = ((c < 0.f) ? -1.f : 1.f) * m * h;
     float ss = (float)F->ss, ts = (float)F->ts, a = v[F->sa], b = v[F->ta];
     g0[F->sa] = dw[0] * ss * h;  g0[F->ta] = dw[2] * ts * h;  g0[F->ma] = -k * (dw[0] * ss * a + dw[2] * ts * b);

@@ -7,18 +7,59 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+REFERENCE_ROOT = "/root/reference"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
 @pytest.fixture(scope="session")
-def oracle():
-    """The CPU oracle (test infrastructure); compiled on demand with gcc."""
+def ref():
+    """The reference itself compiled for the host (oracle/_ref, see oracle/ref.py).  Built on demand where
+    the reference checkout exists; on the GPU box the prebuilt binary travels with the snapshot.  Tests that
+    need it are skipped only when neither is there."""
+    from oracle import ref as _ref
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "csrc")):
+        _ref.build()
+    if not _ref.available():
+        pytest.skip("oracle/_ref not built and %s absent" % REFERENCE_ROOT)
+    _ref.lib()
+    return _ref
+
+
+@pytest.fixture(scope="session")
+def raw_oracle():
+    """The C oracle without the reference cross-check."""
     import oracle as _oracle
     _oracle.build()
     _oracle.lib()
     return _oracle
+
+
+@pytest.fixture(scope="session")
+def oracle(raw_oracle):
+    """The CPU oracle (test infrastructure), pinned: every call is also run through the reference's own code
+    when oracle/_ref is available and must agree with it (oracle/pinned.py)."""
+    from oracle import ref as _ref
+    from oracle.pinned import PinnedOracle
+    if os.path.isdir(os.path.join(REFERENCE_ROOT, "csrc")):
+        _ref.build()
+    po = PinnedOracle(raw_oracle)
+    pytest._nvdr_pinned = po
+    return po
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How much of the run was checked against the reference itself."""
+    try:
+        from oracle.pinned import PinnedOracle  # noqa: F401
+    except Exception:  # noqa: BLE001
+        return
+    po = getattr(pytest, "_nvdr_pinned", None)
+    if po is not None and po.stats:
+        terminalreporter.write_line("oracle pinned to the reference (%s): " % ("enabled" if po.enabled else "DISABLED") +
+                                    ", ".join("%s x%d (worst %.2f of tol)" % (k, v[0], v[1]) for k, v in sorted(po.stats.items())))
 
 
 @pytest.fixture(scope="session")

@@ -157,3 +157,40 @@ def test_scratch_clean_state_machine():
     st.mark_clean((2, 100, 64, 64))
     buf3, clean = st.get_scratch(4096, cpu, (2, 100, 64, 64))
     assert not clean and buf3 is not buf               # buffer had to grow: new memory
+
+
+def test_scratch_of_a_captured_context_is_never_called_clean(monkeypatch, capfd):
+    """hipGraph capture freezes the scratch address and the scratch_clean flag into the recorded launches, and the
+    graph may be replayed after other layouts used the buffer: calls recorded during capture, and every later call
+    of such a context, must pass scratch_clean = 0, and a buffer a graph may point to must stay alive when the
+    context outgrows it.  Growth is reported like RasterImpl.cpp:189-197 (INFO, 10 MB granularity)."""
+    import torch
+    from nvdiffrast_amd.torch import _plugin
+    st = _plugin.RasterizeCRStateWrapper(0)
+    cpu = torch.device("cpu")
+    a, b = (4, 100, 64, 64), (1, 100, 32, 32)
+    buf, _ = st.get_scratch(1024, cpu, a)
+    st.mark_clean(a)
+    monkeypatch.setattr(_plugin, "_is_capturing", lambda device: True)
+    _, clean = st.get_scratch(1024, cpu, a)
+    assert not clean and st.captured                   # recorded call: the memset is part of the graph
+    st.mark_clean(a)
+    monkeypatch.setattr(_plugin, "_is_capturing", lambda device: False)
+    _, clean = st.get_scratch(1024, cpu, a)
+    assert not clean                                   # a replay with another layout may have run in between
+    st.mark_clean(a)
+    big, clean = st.get_scratch(1 << 20, cpu, b)
+    assert not clean and big is not buf and any(r is buf for r in st.retired)
+
+    _plugin.set_log_level(0)
+    try:
+        st2 = _plugin.RasterizeCRStateWrapper(0)
+        st2.get_scratch(25 << 20, cpu, a)
+        assert "Internal buffers grown to 30 MB" in capfd.readouterr().err
+        st2.get_scratch(26 << 20, cpu, a)                # inside the reported 30 MB: silent
+        assert "grown" not in capfd.readouterr().err
+    finally:
+        _plugin.set_log_level(1)
+    assert _plugin.get_log_level() == 1
+    _plugin.RasterizeCRStateWrapper(0).get_scratch(25 << 20, cpu, a)
+    assert "grown" not in capfd.readouterr().err        # INFO is below the default WARNING threshold
