@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
     __syncthreads();
     const uint32_t maxBits = *s_max;
     if (maxBits == 0u || (p.dbg & 1)) return;               // no contribution anywhere in the block
-    const bool direct = maxBits >= 0x7F800000u;             // inf/NaN present: plain f32 atomics keep the semantics
+    const bool direct = slots == 0 || maxBits >= 0x7F800000u;   // no table (very wide vertices) / inf or NaN present: plain f32 atomics
     const FixedScale fs(direct ? 0x3F800000u : maxBits);
 
     // ---- phase B -----------------------------------------------------------------------
@@ -399,8 +399,10 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
     // LDS vertex table: as many power-of-two slots as fit in 20 KiB (8 workgroups per CU), at most 512.
     int slots = 512;
     while (slots > 32 && (size_t)slots * (8 * A + 6) + 16 > 20 * 1024) slots >>= 1;
+    // Vertices too wide for even the smallest table (A >= 256) go without one: every contribution becomes a
+    // hardware f32 atomic, as in the reference (interpolate.cu:198-210), instead of an error.
+    if ((size_t)slots * (8 * A + 6) + 16 > 64 * 1024) slots = 0;
     const size_t lds = (size_t)slots * (8 * A + 6) + 16;    // sums + key + used-list entry per slot
-    NVDR_REQUIRE(lds <= 64 * 1024, "interpolate_grad: too many attributes (%d) for the LDS accumulator", A);
     const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);
     const bool vec2 = (A == 2) && !((uintptr_t)attr & 7) && !((uintptr_t)dy & 7);
     {
