@@ -169,6 +169,12 @@ __global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p, int 
 
 __device__ __forceinline__ void swapf(float& a, float& b) { const float t = a; a = b; b = t; }
 
+// c * w * half - f and a * b - c * d as nvcc's default -fmad=true fuses them in the reference (antialias.cu:307-325,
+// 346-348,510-517): whether an edge lying exactly on a pixel boundary yields |alpha| = 0.5 (position gradient
+// killed, :541-546) or 0.49999997 depends on it.  Pinned by the fma build of oracle/_ref.
+__device__ __forceinline__ float aa_proj(float c, float w, float half, float f) { return __fmaf_rn(c * w, half, -f); }
+__device__ __forceinline__ float aa_cross(float a, float b, float c, float d)  { return __fmaf_rn(a, b, -(c * d)); }
+
 // One work item: silhouette test and edge crossing; writes the blend back into the item and returns it
 // (0 = no blend) with the two pixel indices.
 __device__ __forceinline__ float aa_analyse_item(const AAParams& p, int item_idx, int& o_pix0, int& o_pix1)
@@ -214,18 +220,18 @@ __device__ __forceinline__ float aa_analyse_item(const AAParams& p, int item_idx
             const float4 c = vb[vi[k]];
             const float4 o = (op < 0) ? c : vb[op];
             const float w = 1.f / c.w, ow = 1.f / o.w;
-            x[k] = c.x * w * p.xh - fx;   y[k] = c.y * w * p.yh - fy;
-            ox[k] = o.x * ow * p.xh - fx; oy[k] = o.y * ow * p.yh - fy;
+            x[k] = aa_proj(c.x, w, p.xh, fx);   y[k] = aa_proj(c.y, w, p.yh, fy);
+            ox[k] = aa_proj(o.x, ow, p.xh, fx); oy[k] = aa_proj(o.y, ow, p.yh, fy);
         }
 
         // Orientation of the triangle and of each "wing" (edge + opposite vertex): an edge whose wing
         // folds to the same side as the triangle is a silhouette (:321-328).
-        const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+        const float bb = aa_cross(x[1] - x[0], y[2] - y[0], x[2] - x[0], y[1] - y[0]);
         bool sil[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int i = (k + 1) % 3, j = (k + 2) % 3;
-            const float wing = (x[i] - ox[k]) * (y[j] - oy[k]) - (x[j] - ox[k]) * (y[i] - oy[k]);
+            const float wing = aa_cross(x[i] - ox[k], y[j] - oy[k], x[j] - ox[k], y[i] - oy[k]);
             sil[k] = same_sign(wing, bb);
         }
         if (!(sil[0] || sil[1] || sil[2])) return 0.f;
@@ -239,7 +245,7 @@ __device__ __forceinline__ float aa_analyse_item(const AAParams& p, int item_idx
         for (int k = 0; k < 3; k++) {
             const int i = (k + 1) % 3, j = (k + 2) % 3;
             ex[k] = x[j] - x[i]; ey[k] = y[j] - y[i];
-            dist[k] = ds * (x[i] * ey[k] - y[i] * ex[k]);
+            dist[k] = ds * aa_cross(x[i], ey[k], y[i], ex[k]);
             if (same_sign(y[i], y[j])) { dist[k] = -kF32Max; ey[k] = 1.f; }     // the edge does not cross the row
         }
         const int di = max_idx3(dist[0], dist[1], dist[2], ey[0], ey[1], ey[2]);
@@ -350,11 +356,11 @@ __global__ __launch_bounds__(256) void k_aa_grad(const AAParams p)
                         const float4 v = ((const float4*)p.pos)[vbase + ve[k]];
                         ca[k] = d ? v.y : v.x; cb[k] = d ? v.x : v.y;
                         rw[k] = 1.f / v.w;
-                        sa[k] = ca[k] * rw[k] * half_a - fa;
-                        sb[k] = cb[k] * rw[k] * half_b - fb;
+                        sa[k] = aa_proj(ca[k], rw[k], half_a, fa);
+                        sb[k] = aa_proj(cb[k], rw[k], half_b, fb);
                     }
                     const float da = sa[1] - sa[0], db = sb[1] - sb[0];
-                    const float cross = sa[0] * db - sb[0] * da;
+                    const float cross = aa_cross(sa[0], db, sb[0], da);
                     const float ib = 1.f / (db + copysignf(1e-3f, db));
                     const float c = cross * ib;
                     // adjoints of the screen-space ends: d c / d sa0 = sb1 / db, d c / d sa1 = -sb0 / db,

@@ -14,6 +14,10 @@
  */
 #include "nvdr_oracle.h"
 
+/* Contraction as nvcc's default (-fmad=true) performs it on the reference's expressions. */
+#define PROJ(c, w, half, f)   fmaf((c) * (w), (half), -(f))          /* c * w * half - f        (antialias.cu:307-318) */
+#define CROSS(a, b, c, d)     fmaf((a), (b), -((c) * (d)))           /* a * b - c * d           (:321-325,346-348,517) */
+
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -146,17 +150,20 @@ static void analyze(const AACfg* p, int px, int py, int pz, int d, AAItem* it)
     float ow0 = 1.f / O0[3], ow1 = 1.f / O1[3], ow2 = 1.f / O2[3];
     float fx = (float)px + .5f - p->xh;
     float fy = (float)py + .5f - p->yh;
-    float x0 = P0[0] * w0 * p->xh - fx, y0 = P0[1] * w0 * p->yh - fy;
-    float x1 = P1[0] * w1 * p->xh - fx, y1 = P1[1] * w1 * p->yh - fy;
-    float x2 = P2[0] * w2 * p->xh - fx, y2 = P2[1] * w2 * p->yh - fy;
-    float ox0 = O0[0] * ow0 * p->xh - fx, oy0 = O0[1] * ow0 * p->yh - fy;
-    float ox1 = O1[0] * ow1 * p->xh - fx, oy1 = O1[1] * ow1 * p->yh - fy;
-    float ox2 = O2[0] * ow2 * p->xh - fx, oy2 = O2[1] * ow2 * p->yh - fy;
+    /* a*b - c and a*b - c*d below are written as the fused operations nvcc's default -fmad=true makes of them
+     * (fma(a, b, -c), fma(a, b, -(c*d))): whether an edge lying exactly on a pixel boundary gives |alpha| = 0.5
+     * (position gradient killed, :541-546) or 0.49999997 depends on it.  Pinned by oracle/_ref's fma build. */
+    float x0 = PROJ(P0[0], w0, p->xh, fx), y0 = PROJ(P0[1], w0, p->yh, fy);
+    float x1 = PROJ(P1[0], w1, p->xh, fx), y1 = PROJ(P1[1], w1, p->yh, fy);
+    float x2 = PROJ(P2[0], w2, p->xh, fx), y2 = PROJ(P2[1], w2, p->yh, fy);
+    float ox0 = PROJ(O0[0], ow0, p->xh, fx), oy0 = PROJ(O0[1], ow0, p->yh, fy);
+    float ox1 = PROJ(O1[0], ow1, p->xh, fx), oy1 = PROJ(O1[1], ow1, p->yh, fy);
+    float ox2 = PROJ(O2[0], ow2, p->xh, fx), oy2 = PROJ(O2[1], ow2, p->yh, fy);
 
-    float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
-    float a0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
-    float a1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
-    float a2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
+    float bb = CROSS(x1 - x0, y2 - y0, x2 - x0, y1 - y0);
+    float a0 = CROSS(x1 - ox0, y2 - oy0, x2 - ox0, y1 - oy0);
+    float a1 = CROSS(x2 - ox1, y0 - oy1, x0 - ox1, y2 - oy1);
+    float a2 = CROSS(x0 - ox2, y1 - oy2, x1 - ox2, y0 - oy2);
     if (!(same_sign(a0, bb) || same_sign(a1, bb) || same_sign(a2, bb))) return;
 
     if (d) { swapf(&x0, &y0); swapf(&x1, &y1); swapf(&x2, &y2); }
@@ -164,9 +171,9 @@ static void analyze(const AACfg* p, int px, int py, int pz, int d, AAItem* it)
     float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
     float dc = -F32_MAX;
     float ds = (tri == tri0) ? 1.f : -1.f;
-    float d0 = ds * (x1 * dy0 - y1 * dx0);
-    float d1 = ds * (x2 * dy1 - y2 * dx1);
-    float d2 = ds * (x0 * dy2 - y0 * dx2);
+    float d0 = ds * CROSS(x1, dy0, y1, dx0);
+    float d1 = ds * CROSS(x2, dy1, y2, dx1);
+    float d2 = ds * CROSS(x0, dy2, y0, dx2);
     if (same_sign(y1, y2)) { d0 = -F32_MAX; dy0 = 1.f; }
     if (same_sign(y2, y0)) { d1 = -F32_MAX; dy1 = 1.f; }
     if (same_sign(y0, y1)) { d2 = -F32_MAX; dy2 = 1.f; }
@@ -280,18 +287,18 @@ int nvdro_antialias_grad(const float* color, const float* rast, const float* pos
         float fx = (float)px + .5f - pxh, fy = (float)py + .5f - pyh;
         if (d) { swapf(&p1x, &p1y); swapf(&p2x, &p2y); swapf(&pxh, &pyh); swapf(&fx, &fy); }
         float w1 = 1.f / p1w, w2 = 1.f / p2w;
-        float x1 = p1x * w1 * pxh - fx, y1 = p1y * w1 * pyh - fy;
-        float x2 = p2x * w2 * pxh - fx, y2 = p2y * w2 * pyh - fy;
+        float x1 = PROJ(p1x, w1, pxh, fx), y1 = PROJ(p1y, w1, pyh, fy);
+        float x2 = PROJ(p2x, w2, pxh, fx), y2 = PROJ(p2y, w2, pyh, fy);
         float dx = x2 - x1, dyy = y2 - y1;
-        float db = x1 * dyy - y1 * dx;
+        float db = CROSS(x1, dyy, y1, dx);
         float ep = copysignf(1e-3f, dyy);
         float iy = 1.f / (dyy + ep);
         float dby = db * iy;
         float iw1 = -w1 * iy * dd, iw2 = w2 * iy * dd;
         float gp1x = iw1 * pxh * y2, gp2x = iw2 * pxh * y1;
         float gp1y = iw1 * pyh * (dby - x2), gp2y = iw2 * pyh * (dby - x1);
-        float gp1w = -(p1x * gp1x + p1y * gp1y) * w1;
-        float gp2w = -(p2x * gp2x + p2y * gp2y) * w2;
+        float gp1w = -fmaf(p1x, gp1x, p1y * gp1y) * w1;
+        float gp2w = -fmaf(p2x, gp2x, p2y * gp2y) * w2;
         if (d) { swapf(&gp1x, &gp1y); swapf(&gp2x, &gp2y); }
         if (fabsf(alpha) >= 0.5f) { gp1x = gp1y = gp1w = 0.f; gp2x = gp2y = gp2w = 0.f; }
         double* q1 = gp + (vb + vi1) * 4; q1[0] += gp1x; q1[1] += gp1y; q1[3] += gp1w;

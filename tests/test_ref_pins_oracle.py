@@ -304,3 +304,31 @@ def test_four_op_chain(po):
     g = po.texture_grad(tex, uv, g_col, uvda, filter_mode="linear-mipmap-linear")
     _ga, g_rast, g_rdb = po.interpolate_grad(b["uv"], ro, b["tri"], g["uv"], rast_db=rdbo, dda=g["uv_da"], diff_attrs="all")
     po.rasterize_grad(b["pos"], b["tri"], ro, g_rast, ddb=g_rdb)
+
+
+def test_knife_edge_silhouettes_are_not_defined_by_the_reference(po, ref):
+    """A silhouette edge lying EXACTLY on a pixel boundary gives the reference a blend weight of +-0 or +-2^-22
+    depending on a single rounding (antialias.cu:307-365), and its backward pass treats the two cases differently:
+    weight bits == 0 -> item skipped (:409), anything else -> full position gradient, which does not scale with the
+    weight (:519-546).  The reference's own two builds (FMA contraction on / off, oracle/refshim/build.py) therefore
+    disagree with each other by O(100) on such an input, while every forward image agrees to 1e-5.  Documented
+    ambiguity: parity of antialias position gradients is claimed for edges in general position only."""
+    pos = np.array([[[-0.7, -0.7, 0, 1], [0.7, 0.7, 0, 1], [-0.7, 0.7, -0.1, 1]]], np.float32)   # y = 0.7 -> row boundary 34.0 of 40
+    tri = np.array([[0, 1, 2]], np.int32)
+    res = (40, 56)
+    rng = np.random.default_rng(2)
+    color = rng.uniform(size=(1,) + res + (4,)).astype(np.float32)
+    dy = rng.normal(size=color.shape).astype(np.float32)
+    ro, _ = po.rasterize(pos, tri, res)
+    fwd = [ref.antialias(color, ro, pos, tri, variant=v) for v in ("fma", "nofma")] + [po._o.antialias(color, ro, pos, tri)]
+    assert np.abs(fwd[0] - fwd[1]).max() <= 1e-5 and np.abs(fwd[0] - fwd[2]).max() <= 1e-5
+    g = [ref.antialias_grad(color, ro, pos, tri, dy, variant=v)[1] for v in ("fma", "nofma")]
+    assert np.abs(g[0] - g[1]).max() > 10.0
+    # general position (no edge on a pixel boundary or through pixel centres -- the diagonal of the triangle above has
+    # slope 5/7 in pixels and passes through centres, the other knife edge: weight exactly +-1/2 kills the gradient,
+    # :541-546): both builds and the oracle agree
+    pos2 = pos.copy(); pos2[0, :, :2] += np.array([[0.0131, -0.0072], [-0.0057, 0.0113], [0.0091, 0.0039]], np.float32)
+    ro2, _ = po.rasterize(pos2, tri, res)
+    g2 = [ref.antialias_grad(color, ro2, pos2, tri, dy, variant=v)[1] for v in ("fma", "nofma")]
+    assert np.abs(g2[0] - g2[1]).max() <= 2e-5 * np.abs(g2[0]).max()
+    po.antialias_grad(color, ro2, pos2, tri, dy)
