@@ -1,9 +1,17 @@
-"""Public API: same names, signatures, defaults and return arities as the reference's
-``nvdiffrast/torch/ops.py`` (cited per function), running on the MI355X plugin.
+"""Operator layer of ``nvdiffrast_amd.torch``: the public functions and classes of the reference's
+``nvdiffrast/torch/ops.py`` (names, argument order, defaults, return arity, error behaviour) on top of the
+MI355X plugin (``_plugin``, the stand-in for the pybind module ``_nvdiffrast_c``).
 
-Autograd wiring follows the reference's five ``torch.autograd.Function`` classes: the
-same tensors are saved, the same backward entry points are chosen, and gradients are
-returned for the same inputs.
+The interface is the reference's; the construction is this package's own.  All four differentiable ops go
+through ONE ``torch.autograd.Function`` (``_Dispatch``) driven by small stateless descriptors
+(``_RasterizeOp``, ``_InterpolateOp``, ``_TextureOp``, ``_AntialiasOp``) that say which plugin entry points
+compute the forward and the gradients and which inputs those gradients belong to; argument checking and mode
+resolution are table driven (``_FILTER_MODES``, ``_BOUNDARY_MODES``) and shared (``_tensors``, ``_as_ranges``,
+``_mip_limit``).  Behaviour that scripts written for the reference rely on is kept deliberately, including its
+quirks -- they are listed where they occur, with the reference line they come from.
+
+``tests/test_capi_exports.py`` compares every public signature with the reference's file, and
+``tests/test_gpu_reference_ops.py`` runs the reference's own ``ops.py`` on ``_plugin`` next to this module.
 """
 import warnings
 
@@ -13,117 +21,267 @@ import torch
 from . import _plugin
 
 __all__ = [
-    "RasterizeCudaContext", "RasterizeGLContext", "get_log_level", "set_log_level",
-    "rasterize", "DepthPeeler", "interpolate",
-    "texture", "texture_construct_mip", "antialias", "antialias_construct_topology_hash",
+    "RasterizeCudaContext", "RasterizeGLContext", "DepthPeeler",
+    "get_log_level", "set_log_level",
+    "rasterize", "interpolate", "texture", "texture_construct_mip",
+    "antialias", "antialias_construct_topology_hash",
 ]
 
-
-# ----------------------------------------------------------------------------- logging
-# reference ops.py:18-41
+# ------------------------------------------------------------------------------------------------
+# Logging passthrough (reference ops.py:18-41): levels are c10's, 0 INFO .. 3 FATAL, default 1.
 
 def get_log_level():
-    """Current log level (0 info, 1 warning, 2 error, 3 fatal)."""
+    """Current log level of the native library (0 = INFO, 1 = WARNING (default), 2 = ERROR, 3 = FATAL)."""
     return _plugin.get_log_level()
 
 
 def set_log_level(level):
-    """Set the log level; messages below it are silent.  Default is 1."""
+    """Set the log level; 0 makes the rasterizer report when its internal buffers grow."""
     _plugin.set_log_level(level)
 
 
-# ----------------------------------------------------------------------------- context
-# reference ops.py:47-68
+# ------------------------------------------------------------------------------------------------
+# Shared argument handling.
 
-class RasterizeCudaContext:
-    """Rasterizer context bound to one GPU.  Holds the rasterizer's scratch memory; it is
-    released with the object.  Not thread-safe, like the reference's."""
-
-    def __init__(self, device=None):
-        if device is None:
-            idx = torch.cuda.current_device()
-        else:
-            with torch.cuda.device(device):
-                idx = torch.cuda.current_device()
-        self.cpp_wrapper = _plugin.RasterizeCRStateWrapper(idx)
-        self.active_depth_peeler = None
+def _tensors(**named):
+    """Every argument must be a torch.Tensor; AssertionError otherwise, as the reference's asserts."""
+    for name, value in named.items():
+        assert isinstance(value, torch.Tensor), f"{name} must be a torch.Tensor"
 
 
-# ----------------------------------------------------------------------------- rasterize
-# reference ops.py:75-135
+def _as_ranges(ranges):
+    """Range-mode table, or the empty CPU [0,2] int32 tensor the plugin expects in instanced mode (ops.py:125-126)."""
+    if ranges is None:
+        return torch.empty(size=(0, 2), dtype=torch.int32, device="cpu")
+    _tensors(ranges=ranges)
+    return ranges
 
-class _rasterize_func(torch.autograd.Function):
+
+def _mip_limit(max_mip_level):
+    """None -> -1 (no limit); otherwise a non-negative int (ops.py:399-403, 458-462)."""
+    if max_mip_level is None:
+        return -1
+    level = int(max_mip_level)
+    assert level >= 0
+    return level
+
+
+_FILTER_MODES = {"nearest": 0, "linear": 1, "linear-mipmap-nearest": 2, "linear-mipmap-linear": 3}   # ops.py:415
+_BOUNDARY_MODES = {"cube": 0, "wrap": 1, "clamp": 2, "zero": 3}                                        # ops.py:417
+_MIPMAPPED = ("linear-mipmap-nearest", "linear-mipmap-linear")
+
+
+# ------------------------------------------------------------------------------------------------
+# One autograd node for every op.
+
+class _Dispatch(torch.autograd.Function):
+    """forward(op, *args) runs ``op.forward``; backward hands the upstream gradients to ``op.backward`` and
+    returns one gradient slot per forward argument (plus None for the descriptor itself)."""
+
     @staticmethod
-    def forward(ctx, raster_ctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
-        out, out_db = _plugin.rasterize_fwd_cuda(raster_ctx.cpp_wrapper, pos, tri, resolution, ranges, peeling_idx)
-        ctx.save_for_backward(pos, tri, out)
-        ctx.saved_grad_db = grad_db
-        # An unused output's gradient arrives as None instead of a materialised zero tensor;
-        # that is 32 B/pixel the reference writes and reads back for nothing (SURVEY 3.2).
-        ctx.set_materialize_grads(False)
-        return out, out_db
+    def forward(ctx, op, *args):
+        outputs, keep, state = op.forward(*args)
+        ctx.op, ctx.state, ctx.arity = op, state, len(args)
+        ctx.save_for_backward(*keep)
+        return outputs
 
     @staticmethod
-    def backward(ctx, dy, ddb):
-        pos, tri, out = ctx.saved_tensors
-        if dy is None and (ddb is None or not ctx.saved_grad_db):
-            return None, None, None, None, None, None, None
-        if dy is None:
-            dy = torch.zeros_like(out)
-        if ctx.saved_grad_db and ddb is not None:
-            g_pos = _plugin.rasterize_grad_db(pos, tri, out, dy, ddb)
+    def backward(ctx, *upstream):
+        grads = ctx.op.backward(ctx.state, ctx.saved_tensors, *upstream)
+        assert len(grads) == ctx.arity
+        return (None,) + tuple(grads)
+
+
+class _RasterizeOp:
+    """args: context, pos, tri, resolution, ranges, grad_db, peeling_idx -> (rast, rast_db); gradient to pos only."""
+
+    @staticmethod
+    def forward(raster_ctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
+        rast, rast_db = _plugin.rasterize_fwd_cuda(raster_ctx.cpp_wrapper, pos, tri, resolution, ranges, peeling_idx)
+        return (rast, rast_db), (pos, tri, rast), bool(grad_db)
+
+    @staticmethod
+    def backward(grad_db, saved, d_rast, d_rast_db):
+        pos, tri, rast = saved
+        if grad_db:
+            g_pos = _plugin.rasterize_grad_db(pos, tri, rast, d_rast, d_rast_db)
         else:
-            g_pos = _plugin.rasterize_grad(pos, tri, out, dy)
+            g_pos = _plugin.rasterize_grad(pos, tri, rast, d_rast)
         return None, g_pos, None, None, None, None, None
 
 
-def _empty_ranges():
-    return torch.empty(size=(0, 2), dtype=torch.int32, device="cpu")
+class _InterpolateOp:
+    """args: attr, rast, tri, rast_db or None, diff_all, diff_list -> (out, out_da)."""
+
+    @staticmethod
+    def forward(attr, rast, tri, rast_db, diff_all, diff_list):
+        with_da = rast_db is not None
+        if with_da:
+            outs = _plugin.interpolate_fwd_da(attr, rast, tri, rast_db, diff_all, diff_list)
+            keep = (attr, rast, tri, rast_db)
+        else:
+            outs = _plugin.interpolate_fwd(attr, rast, tri)
+            keep = (attr, rast, tri)
+        return tuple(outs), keep, (with_da, diff_all, diff_list)
+
+    @staticmethod
+    def backward(state, saved, d_out, d_out_da):
+        with_da, diff_all, diff_list = state
+        if with_da:
+            attr, rast, tri, rast_db = saved
+            g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list)
+            return g_attr, g_rast, None, g_rast_db, None, None
+        attr, rast, tri = saved
+        g_attr, g_rast = _plugin.interpolate_grad(attr, rast, tri, d_out)
+        return g_attr, g_rast, None, None, None, None
+
+
+class _TextureOp:
+    """args: filter_mode, boundary id, tex, uv, uv_da, mip_level_bias, mip wrapper, *custom mip levels -> out.
+    The four gradient entry points of the plugin are selected by filter mode; custom mip levels receive their own
+    gradients (trailing slots)."""
+
+    @staticmethod
+    def forward(filter_mode, boundary, tex, uv, uv_da, mip_level_bias, mip_wrapper, *mip_stack):
+        f = _FILTER_MODES[filter_mode]
+        if filter_mode in _MIPMAPPED:
+            # absent optional tensors travel as empty tensors, an absent wrapper as an empty one (ops.py:301-307)
+            placeholder = torch.tensor([])
+            uv_da = placeholder if uv_da is None else uv_da
+            mip_level_bias = placeholder if mip_level_bias is None else mip_level_bias
+            mip_wrapper = _plugin.TextureMipWrapper() if mip_wrapper is None else mip_wrapper
+            out = _plugin.texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, f, boundary)
+            keep = (tex, uv, uv_da, mip_level_bias) + tuple(mip_stack)
+        else:
+            out = _plugin.texture_fwd(tex, uv, f, boundary)
+            keep = (tex, uv)
+        return out, keep, (filter_mode, f, boundary, mip_wrapper, len(mip_stack))
+
+    @staticmethod
+    def backward(state, saved, d_out):
+        filter_mode, f, boundary, mip_wrapper, n_custom = state
+        g_uv = g_uv_da = g_bias = None
+        g_levels = (None,) * n_custom
+        if filter_mode in _MIPMAPPED:
+            tex, uv, uv_da, bias = saved[:4]
+            stack = list(saved[4:])
+            if filter_mode == "linear-mipmap-linear":
+                g_tex, g_uv, g_uv_da, g_bias, g_stack = _plugin.texture_grad_linear_mipmap_linear(
+                    tex, uv, d_out, uv_da, bias, mip_wrapper, stack, f, boundary)
+            else:
+                g_tex, g_uv, g_stack = _plugin.texture_grad_linear_mipmap_nearest(
+                    tex, uv, d_out, uv_da, bias, mip_wrapper, stack, f, boundary)
+            g_levels = tuple(g_stack)
+        else:
+            tex, uv = saved
+            if filter_mode == "linear":
+                g_tex, g_uv = _plugin.texture_grad_linear(tex, uv, d_out, f, boundary)
+            else:
+                g_tex = _plugin.texture_grad_nearest(tex, uv, d_out, f, boundary)
+        return (None, None, g_tex, g_uv, g_uv_da, g_bias, None) + g_levels
+
+
+class _AntialiasOp:
+    """args: color, rast, pos, tri, topology hash, pos_gradient_boost -> out.  The work buffer written by the
+    forward pass is replayed by the gradient pass (ops.py:476, torch_antialias.cpp:223)."""
+
+    @staticmethod
+    def forward(color, rast, pos, tri, topology_hash, pos_gradient_boost):
+        out, work_buffer = _plugin.antialias_fwd(color, rast, pos, tri, topology_hash)
+        return out, (color, rast, pos, tri), (pos_gradient_boost, work_buffer)
+
+    @staticmethod
+    def backward(state, saved, d_out):
+        boost, work_buffer = state
+        color, rast, pos, tri = saved
+        g_color, g_pos = _plugin.antialias_grad(color, rast, pos, tri, d_out, work_buffer)
+        if boost != 1.0:
+            g_pos = g_pos * boost
+        return g_color, None, g_pos, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Rasterizer contexts and rasterize().
+
+class RasterizeCudaContext:
+    """Rasterizer state for one GPU (reference ops.py:47-68).
+
+    Owns the native rasterizer's scratch memory.  A context belongs to the device it was created for
+    (``device`` or, when None, the current one) and must not be used from two threads at once."""
+
+    def __init__(self, device=None):
+        if device is None:
+            index = torch.cuda.current_device()
+        else:
+            with torch.cuda.device(device):
+                index = torch.cuda.current_device()
+        self.cpp_wrapper = _plugin.RasterizeCRStateWrapper(index)
+        self.active_depth_peeler = None
+
+
+class RasterizeGLContext(RasterizeCudaContext):
+    """Deprecated alias kept for old scripts (reference ops.py:550-559): an OpenGL context never existed here
+    either; ``output_db`` and ``mode`` are accepted and ignored, ``set_context`` / ``release_context`` do nothing."""
+
+    def __init__(self, output_db=True, mode="automatic", device=None):
+        warnings.warn("RasterizeGLContext has been deprecated and uses RasterizeCudaContext internally", DeprecationWarning, stacklevel=2)
+        super().__init__(device=device)
+
+    def set_context(self):
+        pass
+
+    def release_context(self):
+        pass
+
+
+def _raster_request(glctx, pos, tri, resolution, ranges, grad_db):
+    """Validation shared by rasterize() and DepthPeeler (ops.py:118-126, 150-158)."""
+    assert isinstance(glctx, RasterizeCudaContext)
+    assert grad_db is True or grad_db is False
+    _tensors(pos=pos, tri=tri)
+    return tuple(resolution), _as_ranges(ranges)
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
-    """Rasterize triangles (reference ops.py:93-135).
+    """Rasterize triangles.
 
-    pos: [N,V,4] float32 (instanced mode) or [V,4] (range mode, needs ``ranges``);
-    tri: [T,3] int32; resolution: (height, width); ranges: CPU int32 [N,2] (start, count).
-    Returns (rast [N,H,W,4] = (u, v, z/w, triangle_id + 1), rast_db [N,H,W,4] =
-    (du/dX, du/dY, dv/dX, dv/dY)).  ``grad_db`` routes rast_db's gradients into ``pos``.
+    Args:
+        glctx: a ``RasterizeCudaContext``.
+        pos: clip-space vertex positions, float32 on the GPU: ``[minibatch, num_vertices, 4]`` (instanced mode)
+            or ``[num_vertices, 4]`` (range mode).
+        tri: ``[num_triangles, 3]`` int32 vertex indices on the GPU.
+        resolution: ``(height, width)`` of the output.
+        ranges: range mode only -- int32 CPU tensor ``[minibatch, 2]`` of (first triangle, triangle count).
+        grad_db: propagate gradients of the second output to ``pos``.
+
+    Returns:
+        ``(rast, rast_db)``, both ``[minibatch, height, width, 4]`` float32: ``rast`` = (u, v, z/w, triangle_id + 1
+        or 0 for background), ``rast_db`` = (du/dX, du/dY, dv/dX, dv/dY).  Row 0 is the bottom scan line.
+
+    Reference quirk kept: while a ``DepthPeeler`` is active on ``glctx`` this RETURNS (does not raise) a
+    ``RuntimeError`` instance (ops.py:131-132).
     """
-    assert isinstance(glctx, RasterizeCudaContext)
-    assert grad_db is True or grad_db is False
-    assert isinstance(pos, torch.Tensor) and isinstance(tri, torch.Tensor)
-    resolution = tuple(resolution)
-    if ranges is None:
-        ranges = _empty_ranges()
-    else:
-        assert isinstance(ranges, torch.Tensor)
+    resolution, ranges = _raster_request(glctx, pos, tri, resolution, ranges, grad_db)
     if glctx.active_depth_peeler is not None:
-        # The reference returns (does not raise) this error object (ops.py:131-132).
         return RuntimeError("Cannot call rasterize() during depth peeling operation, use rasterize_next_layer() instead")
-    return _rasterize_func.apply(glctx, pos, tri, resolution, ranges, grad_db, -1)
+    return _Dispatch.apply(_RasterizeOp, glctx, pos, tri, resolution, ranges, grad_db, -1)
 
-
-# ----------------------------------------------------------------------------- depth peeling
-# reference ops.py:141-204
 
 class DepthPeeler:
-    """Context manager that rasterizes successive depth layers; arguments as ``rasterize()``."""
+    """Context manager that peels depth layers front to back (reference ops.py:141-204)::
+
+        with DepthPeeler(glctx, pos, tri, resolution) as peeler:
+            for _ in range(num_layers):
+                rast, rast_db = peeler.rasterize_next_layer()
+
+    Only one peeler can be active per context, and a peeler cannot be re-entered after it has exited."""
+
+    _FIELDS = ("raster_ctx", "pos", "tri", "resolution", "ranges", "grad_db", "peeling_idx")
 
     def __init__(self, glctx, pos, tri, resolution, ranges=None, grad_db=True):
-        assert isinstance(glctx, RasterizeCudaContext)
-        assert grad_db is True or grad_db is False
-        assert isinstance(pos, torch.Tensor) and isinstance(tri, torch.Tensor)
-        resolution = tuple(resolution)
-        if ranges is None:
-            ranges = _empty_ranges()
-        else:
-            assert isinstance(ranges, torch.Tensor)
-        self.raster_ctx = glctx
-        self.pos = pos
-        self.tri = tri
-        self.resolution = resolution
-        self.ranges = ranges
-        self.grad_db = grad_db
+        resolution, ranges = _raster_request(glctx, pos, tri, resolution, ranges, grad_db)
+        self.raster_ctx, self.pos, self.tri = glctx, pos, tri
+        self.resolution, self.ranges, self.grad_db = resolution, ranges, grad_db
         self.peeling_idx = None
 
     def __enter__(self):
@@ -138,242 +296,146 @@ class DepthPeeler:
     def __exit__(self, *args):
         assert self.raster_ctx.active_depth_peeler is self
         self.raster_ctx.active_depth_peeler = None
-        # Drop every reference to the inputs.
-        self.raster_ctx = self.pos = self.tri = self.resolution = None
-        self.ranges = self.grad_db = self.peeling_idx = None
+        for field in self._FIELDS:                       # drop every reference to the inputs (ops.py:183-190)
+            setattr(self, field, None)
         return None
 
     def rasterize_next_layer(self):
-        """Like ``rasterize()`` but surface points reported by earlier layers are culled."""
+        """Next depth layer: same outputs as ``rasterize()``; pixels no deeper than the previous layer are hidden."""
         assert self.raster_ctx.active_depth_peeler is self
         assert self.peeling_idx >= 0
-        result = _rasterize_func.apply(self.raster_ctx, self.pos, self.tri, self.resolution, self.ranges,
-                                       self.grad_db, self.peeling_idx)
+        layer = self.peeling_idx
         self.peeling_idx += 1
-        return result
+        return _Dispatch.apply(_RasterizeOp, self.raster_ctx, self.pos, self.tri, self.resolution, self.ranges, self.grad_db, layer)
 
 
-# ----------------------------------------------------------------------------- interpolate
-# reference ops.py:211-291
-
-class _interpolate_func_da(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_list):
-        out, out_da = _plugin.interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_list)
-        ctx.save_for_backward(attr, rast, tri, rast_db)
-        ctx.saved_misc = diff_attrs_all, diff_attrs_list
-        return out, out_da
-
-    @staticmethod
-    def backward(ctx, dy, dda):
-        attr, rast, tri, rast_db = ctx.saved_tensors
-        diff_attrs_all, diff_attrs_list = ctx.saved_misc
-        g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, dy, rast_db, dda,
-                                                               diff_attrs_all, diff_attrs_list)
-        return g_attr, g_rast, None, g_rast_db, None, None
-
-
-class _interpolate_func(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, attr, rast, tri):
-        out, out_da = _plugin.interpolate_fwd(attr, rast, tri)
-        ctx.save_for_backward(attr, rast, tri)
-        return out, out_da
-
-    @staticmethod
-    def backward(ctx, dy, _):
-        attr, rast, tri = ctx.saved_tensors
-        g_attr, g_rast = _plugin.interpolate_grad(attr, rast, tri, dy)
-        return g_attr, g_rast, None
-
+# ------------------------------------------------------------------------------------------------
+# interpolate()
 
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
-    """Interpolate vertex attributes (reference ops.py:241-291).
+    """Interpolate vertex attributes over the pixels of a rasterized image.
 
-    attr: [V,A] (range mode) or [N,V,A] / [1,V,A] (instanced, broadcast allowed);
-    diff_attrs: None, 'all' or a list of attribute indices whose image-space derivatives
-    are wanted (needs ``rast_db``).  Returns (out [N,H,W,A], out_da [N,H,W,2*len(diff_attrs)]);
-    out_da has a zero-length last axis when no derivatives are requested.
+    Args:
+        attr: ``[num_vertices, num_attributes]`` (range mode) or ``[minibatch, num_vertices, num_attributes]``
+            (instanced; a minibatch of 1 is broadcast) float32 on the GPU.
+        rast: first output of ``rasterize()``.
+        tri: the triangle tensor used for rasterization.
+        rast_db: second output of ``rasterize()``; needed for attribute pixel differentials.
+        diff_attrs: attribute indices to differentiate with respect to the pixel position, or ``'all'``.
+
+    Returns:
+        ``(out, out_da)``: ``[minibatch, height, width, num_attributes]`` and
+        ``[minibatch, height, width, 2 * len(diff_attrs)]`` as (dA/dX, dA/dY) pairs -- last dimension 0 when no
+        differentials were requested.
     """
+    want_all = isinstance(diff_attrs, str) and diff_attrs == "all"
     if diff_attrs is None:
-        diff_attrs = []
-    elif diff_attrs != 'all':
-        diff_attrs = np.asarray(diff_attrs, np.int32)
-        assert len(diff_attrs.shape) == 1
-        diff_attrs = diff_attrs.tolist()
-    diff_attrs_all = int(diff_attrs == 'all')
-    diff_attrs_list = [] if diff_attrs_all else diff_attrs
-
-    assert all(isinstance(x, torch.Tensor) for x in (attr, rast, tri))
-    if diff_attrs:
-        assert isinstance(rast_db, torch.Tensor)
-        return _interpolate_func_da.apply(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_list)
-    return _interpolate_func.apply(attr, rast, tri)
-
-
-# ----------------------------------------------------------------------------- texture
-# reference ops.py:298-465
-
-class _texture_func_mip(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, filter_mode, tex, uv, uv_da, mip_level_bias, mip_wrapper, filter_mode_enum, boundary_mode_enum, *mip_stack):
-        empty = torch.tensor([])
-        if uv_da is None:
-            uv_da = empty
-        if mip_level_bias is None:
-            mip_level_bias = empty
-        if mip_wrapper is None:
-            mip_wrapper = _plugin.TextureMipWrapper()
-        out = _plugin.texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode_enum, boundary_mode_enum)
-        ctx.save_for_backward(tex, uv, uv_da, mip_level_bias, *mip_stack)
-        ctx.saved_misc = filter_mode, mip_wrapper, filter_mode_enum, boundary_mode_enum
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        tex, uv, uv_da, mip_level_bias, *mip_stack = ctx.saved_tensors
-        filter_mode, mip_wrapper, filter_mode_enum, boundary_mode_enum = ctx.saved_misc
-        if filter_mode == 'linear-mipmap-linear':
-            g_tex, g_uv, g_uv_da, g_mip_level_bias, g_mip_stack = _plugin.texture_grad_linear_mipmap_linear(
-                tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode_enum, boundary_mode_enum)
-            return (None, g_tex, g_uv, g_uv_da, g_mip_level_bias, None, None, None) + tuple(g_mip_stack)
-        else:  # linear-mipmap-nearest
-            g_tex, g_uv, g_mip_stack = _plugin.texture_grad_linear_mipmap_nearest(
-                tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode_enum, boundary_mode_enum)
-            return (None, g_tex, g_uv, None, None, None, None, None) + tuple(g_mip_stack)
-
-
-class _texture_func(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, filter_mode, tex, uv, filter_mode_enum, boundary_mode_enum):
-        out = _plugin.texture_fwd(tex, uv, filter_mode_enum, boundary_mode_enum)
-        ctx.save_for_backward(tex, uv)
-        ctx.saved_misc = filter_mode, filter_mode_enum, boundary_mode_enum
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        tex, uv = ctx.saved_tensors
-        filter_mode, filter_mode_enum, boundary_mode_enum = ctx.saved_misc
-        if filter_mode == 'linear':
-            g_tex, g_uv = _plugin.texture_grad_linear(tex, uv, dy, filter_mode_enum, boundary_mode_enum)
-            return None, g_tex, g_uv, None, None
-        else:  # nearest
-            g_tex = _plugin.texture_grad_nearest(tex, uv, dy, filter_mode_enum, boundary_mode_enum)
-            return None, g_tex, None, None, None
-
-
-def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode='auto', boundary_mode='wrap', max_mip_level=None):
-    """Texture sampling (reference ops.py:345-439).
-
-    tex: [N or 1, Ht, Wt, C] float32, or a cube map [N or 1, 6, S, S, C] with boundary_mode='cube';
-    uv: [N,H,W,2] (cube: direction vectors [N,H,W,3]); uv_da: optional image-space derivatives of uv,
-    [N,H,W,4] (cube: [N,H,W,6]);
-    mip_level_bias: optional [N,H,W]; mip: a ``texture_construct_mip()`` result or a list of tensors
-    (custom mip stack, levels 1..L, which then receive their own gradients); filter_mode: 'auto',
-    'nearest', 'linear', 'linear-mipmap-nearest', 'linear-mipmap-linear' ('auto' = trilinear when
-    uv_da or mip_level_bias is given, else 'linear'); boundary_mode: 'wrap', 'clamp', 'zero', 'cube';
-    max_mip_level limits the mip chain.  Returns [N,H,W,C].
-    """
-    if filter_mode == 'auto':
-        filter_mode = 'linear-mipmap-linear' if (uv_da is not None or mip_level_bias is not None) else 'linear'
-    if max_mip_level is None:
-        max_mip_level = -1
+        selected = []
+    elif want_all:
+        selected = []
     else:
-        max_mip_level = int(max_mip_level)
-        assert max_mip_level >= 0
-    assert isinstance(tex, torch.Tensor) and isinstance(uv, torch.Tensor)
-    if 'mipmap' in filter_mode:
+        arr = np.asarray(diff_attrs, np.int32)
+        assert len(arr.shape) == 1
+        selected = arr.tolist()
+    _tensors(attr=attr, rast=rast, tri=tri)
+    if want_all or selected:
+        _tensors(rast_db=rast_db)
+        return _Dispatch.apply(_InterpolateOp, attr, rast, tri, rast_db, int(want_all), selected)
+    return _Dispatch.apply(_InterpolateOp, attr, rast, tri, None, 0, [])
+
+
+# ------------------------------------------------------------------------------------------------
+# texture()
+
+def _resolve_filter_mode(filter_mode, uv_da, mip_level_bias, max_mip_level):
+    """'auto' picks the best mode the inputs allow (ops.py:395-396); a mip chain limited to level 0 is plain
+    bilinear filtering (ops.py:411-412)."""
+    if filter_mode == "auto":
+        filter_mode = "linear-mipmap-linear" if (uv_da is not None or mip_level_bias is not None) else "linear"
+    if "mipmap" in filter_mode:
         assert isinstance(uv_da, torch.Tensor) or isinstance(mip_level_bias, torch.Tensor)
-    if max_mip_level == 0 and filter_mode in ['linear-mipmap-nearest', 'linear-mipmap-linear']:
-        filter_mode = 'linear'
-    filter_mode_dict = {'nearest': 0, 'linear': 1, 'linear-mipmap-nearest': 2, 'linear-mipmap-linear': 3}
-    filter_mode_enum = filter_mode_dict[filter_mode]
-    boundary_mode_dict = {'cube': 0, 'wrap': 1, 'clamp': 2, 'zero': 3}
-    boundary_mode_enum = boundary_mode_dict[boundary_mode]
-    if 'mipmap' in filter_mode:
-        mip_wrapper, mip_stack = None, []
-        if mip is not None:
-            assert isinstance(mip, (_plugin.TextureMipWrapper, list))
-            if isinstance(mip, list):
-                assert all(isinstance(x, torch.Tensor) for x in mip)
-                mip_stack = mip
-            else:
-                mip_wrapper = mip
+    if max_mip_level == 0 and filter_mode in _MIPMAPPED:
+        filter_mode = "linear"
+    return filter_mode
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="auto", boundary_mode="wrap", max_mip_level=None):
+    """Sample a texture.
+
+    Args:
+        tex: ``[minibatch, tex_height, tex_width, channels]`` or, for cube maps (``boundary_mode='cube'``),
+            ``[minibatch, 6, size, size, channels]``; float32 on the GPU; a minibatch of 1 is broadcast.
+        uv: ``[minibatch, height, width, 2]`` texture coordinates (cube maps: ``[..., 3]`` direction vectors).
+        uv_da: pixel differentials of ``uv`` (last dimension twice that of ``uv``), selects the mip level.
+        mip_level_bias: ``[minibatch, height, width]`` added to the mip level; alone, it IS the level.
+        mip: a stack from ``texture_construct_mip()``, or a list of tensors (levels 1.. of a custom stack, which
+            then receive their own gradients instead of passing them on to ``tex``).  Built internally when a
+            mipmapped mode needs one and none is given.
+        filter_mode: ``'auto'``, ``'nearest'``, ``'linear'``, ``'linear-mipmap-nearest'`` or ``'linear-mipmap-linear'``.
+        boundary_mode: ``'wrap'``, ``'clamp'``, ``'zero'`` or ``'cube'``.
+        max_mip_level: limit on the number of mip levels built and used.
+
+    Returns:
+        ``[minibatch, height, width, channels]``.  Invalid cube-map directions (e.g. zero vectors) give zeros
+        and no gradients.
+    """
+    limit = _mip_limit(max_mip_level)
+    _tensors(tex=tex, uv=uv)
+    filter_mode = _resolve_filter_mode(filter_mode, uv_da, mip_level_bias, limit)
+    _FILTER_MODES[filter_mode]                              # KeyError for an unknown mode, as the reference's dict lookup
+    boundary = _BOUNDARY_MODES[boundary_mode]
+    if filter_mode not in _MIPMAPPED:
+        return _Dispatch.apply(_TextureOp, filter_mode, boundary, tex, uv, None, None, None)
+    wrapper, levels = None, []
+    if mip is None:
+        wrapper = _plugin.texture_construct_mip(tex, limit, boundary_mode == "cube")
+    else:
+        assert isinstance(mip, (_plugin.TextureMipWrapper, list))
+        if isinstance(mip, list):
+            assert all(isinstance(level, torch.Tensor) for level in mip)
+            levels = mip
         else:
-            mip_wrapper = _plugin.texture_construct_mip(tex, max_mip_level, boundary_mode == 'cube')
-    if filter_mode == 'linear-mipmap-linear' or filter_mode == 'linear-mipmap-nearest':
-        return _texture_func_mip.apply(filter_mode, tex, uv, uv_da, mip_level_bias, mip_wrapper,
-                                       filter_mode_enum, boundary_mode_enum, *mip_stack)
-    return _texture_func.apply(filter_mode, tex, uv, filter_mode_enum, boundary_mode_enum)
+            wrapper = mip
+    return _Dispatch.apply(_TextureOp, filter_mode, boundary, tex, uv, uv_da, mip_level_bias, wrapper, *levels)
 
 
 def texture_construct_mip(tex, max_mip_level=None, cube_mode=False):
-    """Build the mip stack of a constant texture once (reference ops.py:442-465); pass the result as ``mip=``."""
-    assert isinstance(tex, torch.Tensor)
+    """Build the mip stack of a texture once, for reuse through ``texture(..., mip=...)`` while the texture
+    stays constant.  ``cube_mode`` must be True for cube maps.  Returns an opaque object."""
+    _tensors(tex=tex)
     assert cube_mode is True or cube_mode is False
-    if max_mip_level is None:
-        max_mip_level = -1
-    else:
-        max_mip_level = int(max_mip_level)
-        assert max_mip_level >= 0
-    return _plugin.texture_construct_mip(tex, max_mip_level, cube_mode)
+    return _plugin.texture_construct_mip(tex, _mip_limit(max_mip_level), cube_mode)
 
 
-# ----------------------------------------------------------------------------- antialias
-# reference ops.py:471-544
-
-class _antialias_func(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, color, rast, pos, tri, topology_hash, pos_gradient_boost):
-        out, work_buffer = _plugin.antialias_fwd(color, rast, pos, tri, topology_hash)
-        ctx.save_for_backward(color, rast, pos, tri)
-        ctx.saved_misc = pos_gradient_boost, work_buffer
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        color, rast, pos, tri = ctx.saved_tensors
-        pos_gradient_boost, work_buffer = ctx.saved_misc
-        g_color, g_pos = _plugin.antialias_grad(color, rast, pos, tri, dy, work_buffer)
-        if pos_gradient_boost != 1.0:
-            g_pos = g_pos * pos_gradient_boost
-        return g_color, None, g_pos, None, None, None
-
+# ------------------------------------------------------------------------------------------------
+# antialias()
 
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
-    """Silhouette antialiasing (reference ops.py:489-526).
+    """Blend silhouette pixels according to the coverage of the edge that crosses them, which is what gives
+    vertex positions a gradient through visibility.
 
-    color: [N,H,W,C]; rast: main output of ``rasterize()``; pos, tri: as given to ``rasterize()``.
-    A vertex shared by several triangles must use one index everywhere, otherwise its edges count as
-    silhouettes.  ``topology_hash``: optional ``antialias_construct_topology_hash(tri)`` result;
-    ``pos_gradient_boost`` scales the gradient that reaches ``pos``.  Returns [N,H,W,C].
+    Silhouettes are found through shared vertex INDICES in ``tri``: a vertex used by several triangles must be
+    referenced by the same index everywhere, otherwise every edge around it counts as a silhouette.
+
+    Args:
+        color: ``[minibatch, height, width, channels]`` image to antialias.
+        rast: first output of ``rasterize()``; pos, tri: the tensors that were rasterized.
+        topology_hash: result of ``antialias_construct_topology_hash(tri)`` (built internally when omitted).
+        pos_gradient_boost: multiplier for the gradient that reaches ``pos``.
+
+    Returns:
+        The antialiased image, same shape as ``color``.
     """
-    assert all(isinstance(x, torch.Tensor) for x in (color, rast, pos, tri))
-    if topology_hash is not None:
-        assert isinstance(topology_hash, _plugin.TopologyHashWrapper)
-    else:
+    _tensors(color=color, rast=rast, pos=pos, tri=tri)
+    if topology_hash is None:
         topology_hash = _plugin.antialias_construct_topology_hash(tri)
-    return _antialias_func.apply(color, rast, pos, tri, topology_hash, pos_gradient_boost)
+    else:
+        assert isinstance(topology_hash, _plugin.TopologyHashWrapper)
+    return _Dispatch.apply(_AntialiasOp, color, rast, pos, tri, topology_hash, pos_gradient_boost)
 
 
 def antialias_construct_topology_hash(tri):
-    """Build the topology hash of a constant triangle tensor once (reference ops.py:529-544)."""
-    assert isinstance(tri, torch.Tensor)
+    """Build the edge -> opposite-vertex table of a triangle tensor once, for reuse through
+    ``antialias(..., topology_hash=...)`` while the topology stays constant.  Returns an opaque object."""
+    _tensors(tri=tri)
     return _plugin.antialias_construct_topology_hash(tri)
-
-
-# ----------------------------------------------------------------------------- legacy GL stub
-# reference ops.py:550-559
-
-class RasterizeGLContext(RasterizeCudaContext):
-    def __init__(self, output_db=True, mode='automatic', device=None):
-        warnings.warn("RasterizeGLContext has been deprecated and uses RasterizeCudaContext internally",
-                      DeprecationWarning, stacklevel=2)
-        super().__init__(device=device)
-
-    def set_context(self):
-        pass
-
-    def release_context(self):
-        pass

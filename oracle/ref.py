@@ -135,7 +135,8 @@ class RasterizeCRStateWrapper:
 
 
 class TextureMipWrapper:
-    def __init__(self, L, h=None, mip=None):
+    def __init__(self, L=None, h=None, mip=None):
+        L = L or lib()
         self.L = L
         self.h = ctypes.c_void_p(L.nvdr_ref_mip_wrapper_empty()) if h is None else h
         self.mip = mip

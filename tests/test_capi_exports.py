@@ -194,3 +194,81 @@ def test_scratch_of_a_captured_context_is_never_called_clean(monkeypatch, capfd)
     assert _plugin.get_log_level() == 1
     _plugin.RasterizeCRStateWrapper(0).get_scratch(25 << 20, cpu, a)
     assert "grown" not in capfd.readouterr().err        # INFO is below the default WARNING threshold
+
+
+REFERENCE_OPS = "/root/reference/nvdiffrast/torch/ops.py"
+
+
+def _public_signatures(source):
+    """{name: [(param, default repr or None), ...]} of every public function, class constructor and public method."""
+    import ast
+    tree = ast.parse(source)
+
+    def params(fn):
+        a = fn.args
+        names = [x.arg for x in a.args]
+        defaults = [None] * (len(names) - len(a.defaults)) + [ast.unparse(d).replace('"', "'") for d in a.defaults]
+        out = list(zip(names, defaults))
+        if a.vararg:
+            out.append(("*" + a.vararg.arg, None))
+        return out
+
+    sigs = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and not node.name.startswith("_"):
+            sigs[node.name] = params(node)
+        elif isinstance(node, ast.ClassDef) and not node.name.startswith("_"):
+            sigs[node.name] = [b.id if isinstance(b, ast.Name) else ast.unparse(b) for b in node.bases]
+            for m in node.body:
+                if isinstance(m, ast.FunctionDef) and (not m.name.startswith("_") or m.name in ("__init__", "__enter__", "__exit__")):
+                    sigs[node.name + "." + m.name] = params(m)
+    return sigs
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_OPS), reason="reference checkout absent")
+def test_every_public_signature_equals_the_reference_file():
+    """Names, parameter names, order and defaults of every public function / class / method of the reference's
+    ops.py (ops.py:18-559), compared syntactically with this package's ops.py."""
+    ours = _public_signatures(open(os.path.join(ROOT, "nvdiffrast_amd", "torch", "ops.py")).read())
+    theirs = _public_signatures(open(REFERENCE_OPS).read())
+    assert set(theirs) <= set(ours), sorted(set(theirs) - set(ours))
+    for name, sig in theirs.items():
+        assert ours[name] == sig, (name, ours[name], sig)
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_OPS), reason="reference checkout absent")
+def test_operator_layer_is_not_a_copy_of_the_reference_file():
+    """The interface must match, the text must not: fewer than a third of this package's code lines (docstrings
+    and comments stripped) may appear verbatim in the reference's ops.py."""
+    import ast
+    import io
+    import tokenize
+
+    def code_lines(path):
+        src = open(path).read()
+        tree = ast.parse(src)
+        doc_lines = set()
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef, ast.Module)) and node.body and isinstance(node.body[0], ast.Expr) \
+                    and isinstance(getattr(node.body[0], "value", None), ast.Constant) and isinstance(node.body[0].value.value, str):
+                doc_lines.update(range(node.body[0].lineno, node.body[0].end_lineno + 1))
+        comment_cols = {}
+        for tok in tokenize.generate_tokens(io.StringIO(src).readline):
+            if tok.type == tokenize.COMMENT:
+                comment_cols[tok.start[0]] = tok.start[1]
+        out = []
+        for i, line in enumerate(src.splitlines(), 1):
+            if i in doc_lines:
+                continue
+            if i in comment_cols:
+                line = line[:comment_cols[i]]
+            line = line.strip()
+            if line:
+                out.append(line)
+        return out
+
+    ours = code_lines(os.path.join(ROOT, "nvdiffrast_amd", "torch", "ops.py"))
+    theirs = set(l.replace("_nvdiffrast_c", "_plugin") for l in code_lines(REFERENCE_OPS))
+    trivial = {"pass", "else:", "return None", "@staticmethod", "import torch", "import warnings", "import numpy as np"}
+    same = [l for l in ours if l in theirs and l not in trivial]
+    assert len(same) < len(ours) / 3, (len(same), len(ours))
