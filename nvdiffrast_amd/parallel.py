@@ -69,11 +69,20 @@ def allreduce_shared_grads(params):
 
 
 def gather_items(local, n_items=None):
-    """All-gather per-item tensors along dim 0 (ragged splits are padded to the largest shard)."""
+    """All-gather per-item tensors along dim 0 (ragged splits are padded to the largest shard).
+
+    ``n_items`` = size of the whole batch when it was split with ``shard_range``; when it is not given the
+    ranks first exchange their local counts, so that every rank sizes the collective identically whatever the split."""
     w = world()
     if w == 1:
         return local
-    counts = [shard_range(n_items if n_items is not None else local.shape[0] * w, w, r)[1] for r in range(w)]
+    if n_items is not None:
+        counts = [shard_range(n_items, w, r)[1] for r in range(w)]
+    else:
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        every = torch.empty(w, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(every, mine)
+        counts = [int(c) for c in every.tolist()]
     mx = max(counts)
     if local.shape[0] < mx:
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -83,3 +92,24 @@ def gather_items(local, n_items=None):
     if all(c == mx for c in counts):
         return out
     return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(w)], 0)
+
+
+def gather_items_async(local, out=None):
+    """Non-blocking all-gather of EQUAL-sized per-item shards along dim 0 -> (work, gathered).
+
+    The collective is issued on the backend's own stream (RCCL: ordered after the kernels that produced ``local``
+    on the current stream), so kernels launched afterwards overlap it; ``work.wait()`` makes the current stream
+    wait for the result.  ``out`` = receive buffer of a previous call to reuse.  World size 1: (no-op work, local)."""
+    w = world()
+    if w == 1:
+        return _Done(), local
+    shape = (w * local.shape[0],) + tuple(local.shape[1:])
+    if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
+        out = torch.empty(shape, dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out, local.contiguous(), async_op=True)
+    return work, out
+
+
+class _Done:
+    def wait(self):
+        return True
