@@ -83,10 +83,16 @@ class _Dispatch(torch.autograd.Function):
         outputs, keep, state = op.forward(*args)
         ctx.op, ctx.state, ctx.arity = op, state, len(args)
         ctx.save_for_backward(*keep)
+        # The gradient of an output nobody used arrives as None instead of a materialised zero tensor: for
+        # rasterize that is 32 B/pixel of zeros the reference writes and reads back for nothing (its rast_db
+        # gradient when only `rast` is consumed).  Descriptors treat None as "no contribution".
+        ctx.set_materialize_grads(False)
         return outputs
 
     @staticmethod
     def backward(ctx, *upstream):
+        if all(g is None for g in upstream):
+            return (None,) * (ctx.arity + 1)
         grads = ctx.op.backward(ctx.state, ctx.saved_tensors, *upstream)
         assert len(grads) == ctx.arity
         return (None,) + tuple(grads)
@@ -103,7 +109,11 @@ class _RasterizeOp:
     @staticmethod
     def backward(grad_db, saved, d_rast, d_rast_db):
         pos, tri, rast = saved
-        if grad_db:
+        if d_rast is None:
+            if not grad_db:
+                return (None,) * 7
+            d_rast = torch.zeros_like(rast)
+        if grad_db and d_rast_db is not None:
             g_pos = _plugin.rasterize_grad_db(pos, tri, rast, d_rast, d_rast_db)
         else:
             g_pos = _plugin.rasterize_grad(pos, tri, rast, d_rast)
@@ -127,6 +137,12 @@ class _InterpolateOp:
     @staticmethod
     def backward(state, saved, d_out, d_out_da):
         with_da, diff_all, diff_list = state
+        if d_out is None:
+            d_out = torch.zeros(tuple(saved[1].shape[:3]) + (saved[0].shape[-1],), dtype=saved[0].dtype, device=saved[0].device)
+        if with_da and d_out_da is None:                 # differentials computed but unused: the plain gradient is the same
+            attr, rast, tri, _rast_db = saved
+            g_attr, g_rast = _plugin.interpolate_grad(attr, rast, tri, d_out)
+            return g_attr, g_rast, None, None, None, None
         if with_da:
             attr, rast, tri, rast_db = saved
             g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list)
