@@ -5,9 +5,10 @@ algorithms, see ``nvdr_oracle.h`` for the file:line citations).  Only ``tests/``
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
 package; the product path (``nvdiffrast_amd``) never does.
 
-Parity status: pinned bit-for-bit against the reference's only golden
-(``docs/img/tri.png`` -> ``tests/golden/tri.png``); everything else is
-"parity unpinned" (the reference is CUDA-only and has no tests).
+Parity status: PINNED.  Tests use this package through ``oracle.pinned.PinnedOracle``, which runs every call
+also through the reference itself (``oracle/_ref``: the reference's own sources compiled for the host, see
+``oracle/ref.py``) and requires agreement; ``docs/img/tri.png`` and ``tests/golden/reference_pipeline.npz``
+(vectors produced by the reference) are reproduced as well.
 """
 import ctypes
 import os

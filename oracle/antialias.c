@@ -5,7 +5,8 @@
  * :165-214 (discontinuity finder), :219-382 (analysis + blend), :387-556 (gradients) and
  * csrc/torch/torch_antialias.cpp:68-241 (xh = W/2, yh = H/2, out = color.clone(), g_color = dy.clone()).
  *
- * Parity unpinned (no golden vectors in the reference).  The reference blends with f32 atomics in
+ * Pinned to the reference itself (oracle/_ref, oracle/pinned.py; edges in general position, see DESIGN.md
+ * "knife-edge silhouettes").  The reference blends with f32 atomics in
  * a scheduling-dependent order; the oracle sums every pixel's / vertex's contributions in f64 in
  * work-item order (pixel-major, "right" item before "down" item) and rounds once.
  * The topology map is an exact edge -> (first, second distinct opposite vertex) table filled in

@@ -7,11 +7,11 @@
  * product path may import, link or call it.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg use it.
  *
- * Parity pinning: the reference has no tests and cannot be compiled here (CUDA
- * only).  The oracle is pinned against the reference's single known-answer
- * artefact, docs/img/tri.png (tests/golden/tri.png), bit-for-bit.  Everything the
- * image does not pin (depth ties, clipping, gradients, texture, antialias) is
- * "parity unpinned": the oracle follows the cited reference lines, nothing more.
+ * Parity pinning: the reference has no tests of its own, but its sources compile for
+ * the host on the CUDA-on-CPU shim of oracle/refshim/ (-> oracle/_ref).  Every test
+ * call into this library is also run through that build and must agree with it
+ * (oracle/pinned.py; tests/test_ref_pins_oracle.py); docs/img/tri.png and the vectors
+ * of tests/golden/reference_pipeline.npz (produced by the reference) are reproduced.
  *
  * All pointers are HOST pointers.  Layouts are the reference's: contiguous
  * [N,H,W,C] f32, row 0 = bottom scanline; pos [N,V,4] (instanced) or [V,4] +

@@ -4,8 +4,9 @@
  * is written explicitly (fmaf) at the sites where nvcc's default -fmad=true would
  * contract the reference expression; all other float ops round separately.
  *
- * Parity: pinned bit-for-bit against docs/img/tri.png only; depth ties, clipping and
- * the FMA sites are unpinned (the reference cannot run here).
+ * Parity: triangle ids identical to the reference's own CudaRaster (oracle/_ref, FMA build) on every test
+ * scene -- snapping, culls, clipper, depth ties, peeling, range mode, viewport tiling -- and docs/img/tri.png
+ * bit for bit.  Where contraction decides a depth comparison the reference's two builds bracket the result.
  */
 #include "nvdr_oracle.h"
 

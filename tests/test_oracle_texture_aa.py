@@ -1,7 +1,7 @@
 """The CPU oracle's texture and antialias restatements checked against independent statements of
 the same maths (numpy bilinear sampling, box-filter mips, adjoint identities, central
-differences, analytic coverage).  The reference holds no golden vectors for these ops
-("parity unpinned"), so these properties are what pins the oracle.  No GPU needed."""
+differences, analytic coverage).  These property tests predate oracle/_ref; every oracle call in them is
+now also cross-checked against the reference itself by the pinned `oracle` fixture.  No GPU needed."""
 import numpy as np
 import pytest
 
