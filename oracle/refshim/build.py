@@ -82,7 +82,7 @@ def build(reference=DEFAULT_REF, force=False, verbose=True):
         raise FileNotFoundError("reference checkout not found at %s" % reference)
     os.makedirs(OUT_DIR, exist_ok=True)
     ref_files = [os.path.join(reference, s) for s in HOST_SOURCES + DEVICE_SOURCES + [CUDARASTER_KERNEL, UTIL_INL]]
-    own_files = [os.path.join(HERE, s) for s in SHIM_SOURCES] + [os.path.abspath(__file__)]
+    own_files = [os.path.join(HERE, s) for s in SHIM_SOURCES + ["cover_probe.cpp"]] + [os.path.abspath(__file__)]
     for root, _d, files in os.walk(os.path.join(HERE, "include")):
         own_files += [os.path.join(root, f) for f in files]
     variants = [("libnvdr_ref.so", ["-mfma", "-ffp-contract=fast"]),
@@ -128,6 +128,8 @@ def build(reference=DEFAULT_REF, force=False, verbose=True):
             jobs.append((os.path.join(gen, "RasterImpl_kernel.cu"), os.path.join(odir, "RasterImpl_kernel.o"), fp_flags + DEVICE_FLAGS))
             for s in SHIM_SOURCES:
                 jobs.append((os.path.join(HERE, s), os.path.join(odir, s + ".o"), fp_flags))
+            # probe into Util.inl's coverage functions: device code, resolves "Util.inl" to the patched copy
+            jobs.append((os.path.join(HERE, "cover_probe.cpp"), os.path.join(odir, "cover_probe.o"), fp_flags + DEVICE_FLAGS + ["-I", gen]))
             with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
                 objs = list(ex.map(compile_one, jobs))
             out = os.path.join(OUT_DIR, lib_name)

@@ -332,3 +332,43 @@ def test_knife_edge_silhouettes_are_not_defined_by_the_reference(po, ref):
     g2 = [ref.antialias_grad(color, ro2, pos2, tri, dy, variant=v)[1] for v in ("fma", "nofma")]
     assert np.abs(g2[0] - g2[1]).max() <= 2e-5 * np.abs(g2[0]).max()
     po.antialias_grad(color, ro2, pos2, tri, dy)
+
+
+def test_lut_coverage_equals_the_integer_fill_rule(ref):
+    """the reference's LIVE fine-raster coverage is the LUT path (Util.inl:214-300,
+    cover8x8_exact_fast with flip bits from cover8x8_selectFlips), while the oracle and the HIP kernel implement the
+    integer rule that Util.inl:304-359 states without a LUT: pixel (x, y) of a tile is inside an edge iff
+        (ox - 16x) * dy - (oy - 16y) * dx - [dy > 0 or (dy == 0 and dx <= 0)]  >=  0
+    (subpixel units; the bracket is the top-left exclusion).  Both reference functions are compiled from the
+    reference's own Util.inl (oracle/refshim/cover_probe.cpp) and compared with each other and with that rule on
+    400k edges: random ones inside a 2048-px viewport, axis-aligned ones, and edges through pixel centres."""
+    import ctypes
+    rng = np.random.default_rng(314)
+    n = 300000
+    base = rng.integers(-16384, 16384 - 128, size=(n, 2)) & ~127                     # tile origins: multiples of 8 px
+    v0 = rng.integers(-16384, 16385, size=(n, 2))
+    v1 = rng.integers(-16384, 16385, size=(n, 2))
+    near = rng.uniform(size=n) < 0.5                                                  # half of the edges close to their tile
+    v0[near] = base[near] + rng.integers(-200, 328, size=(int(near.sum()), 2))
+    v1[near] = v0[near] + rng.integers(-400, 401, size=(int(near.sum()), 2))
+    e = np.concatenate([v0 - base, v1 - v0], 1)
+    # axis-aligned and pixel-centre-aligned edges (the fill rule's tie cases)
+    k = 100000
+    o = rng.integers(-20, 140, size=(k, 2)) * rng.choice([1, 8, 16], size=(k, 1))
+    d = rng.integers(-64, 65, size=(k, 2)) * rng.choice([1, 16], size=(k, 1))
+    d[rng.uniform(size=k) < 0.3, 0] = 0
+    d[rng.uniform(size=k) < 0.3, 1] = 0
+    e = np.ascontiguousarray(np.concatenate([e, np.concatenate([o, d], 1)], 0).astype(np.int32))
+    e = e[(e[:, 2] != 0) | (e[:, 3] != 0)]
+    m = np.zeros((e.shape[0], 2), np.uint64)
+    rc = ref.lib().nvdr_ref_cover8x8_probe(e.ctypes.data_as(ctypes.c_void_p), m.ctypes.data_as(ctypes.c_void_p), int(e.shape[0]))
+    assert rc == 0
+    assert (m[:, 0] != m[:, 1]).sum() == 0, "LUT path and non-LUT statement disagree"
+    ox, oy, dx, dy = [e[:, c].astype(np.int64) for c in range(4)]
+    excl = ((dy > 0) | ((dy == 0) & (dx <= 0))).astype(np.int64)
+    rule = np.zeros(e.shape[0], np.uint64)
+    for y in range(8):
+        for x in range(8):
+            rule |= (((ox - 16 * x) * dy - (oy - 16 * y) * dx - excl) >= 0).astype(np.uint64) << np.uint64(x + 8 * y)
+    assert (rule != m[:, 0]).sum() == 0, "integer fill rule differs from the reference's LUT coverage"
+    assert 0.05 < float((rule != 0).mean()) < 0.95                                    # the sample is not trivial
