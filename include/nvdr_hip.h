@@ -44,8 +44,14 @@ int         nvdr_abi_version(void);
  *                            host glue emits when it regrows the scratch it owns.
  *  NVDR_OPT_CUBE_CORNER_FIX  0 (default): cube-map corner texels exactly as the reference samples them, including
  *                            its loss of the corner flag for texture slices >= 1 (texture_kernel.cu:85-88,431-432);
- *                            1: the missing corner texel is the average of the other three for every slice. */
-enum { NVDR_OPT_LOG_LEVEL = 0, NVDR_OPT_CUBE_CORNER_FIX = 1, NVDR_OPT_COUNT = 2 };
+ *                            1: the missing corner texel is the average of the other three for every slice.
+ *  NVDR_OPT_SCRATCH_LIMIT_MB rasterizer scratch policy of the HOST GLUE (the library itself never allocates): up to this
+ *                            many MiB (default 1024) the glue reserves the worst case -- 6 extra record slots per
+ *                            triangle for the clipper -- so that nothing can overflow and no call ever synchronises
+ *                            the host; above it, it starts from a small clip pool, reads the pool demand back after
+ *                            each call (one host synchronisation, as the reference does every call,
+ *                            RasterImpl.cpp:174-231,367) and repeats the call with a larger pool when it was short. */
+enum { NVDR_OPT_LOG_LEVEL = 0, NVDR_OPT_CUBE_CORNER_FIX = 1, NVDR_OPT_SCRATCH_LIMIT_MB = 2, NVDR_OPT_COUNT = 3 };
 int nvdr_set_option(int option, int value);
 int nvdr_get_option(int option);
 /* Writes `msg` to stderr as "[nvdr] msg" when `severity` >= NVDR_OPT_LOG_LEVEL; returns 1 if it was written. */
@@ -72,6 +78,17 @@ int  nvdr_profile_read(const char** names, double* total_ms, int* launches, int 
  * a memset launch per call.  scratch_clean = 0 is always safe (the library clears the block itself). */
 size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W);
 
+/* The same with a caller-chosen clip pool: `pool_per_image` record slots per image receive the sub-triangles that the
+ * frustum clipper produces beyond the first (a clipped triangle becomes 1..7 sub-triangles); < 0 or >= 6 * max_tri
+ * means the worst case, which is what nvdr_rasterize_scratch_bytes sizes for (record slots are 68 bytes: at
+ * N = 64, T = 1 M the worst case is 30 GB, a pool of T / 4 makes it 5.4 GB).  With a short pool a call can run
+ * out of slots: the sub-triangles that do not fit are left out, and the int at byte offset
+ * nvdr_rasterize_pool_peak_offset(...) of the scratch buffer holds, after the call, the largest per-image demand;
+ * if it exceeds pool_per_image the output is incomplete and the call must be repeated with a larger pool
+ * (the reference sizes its buffers by the same retry, RasterImpl.cpp:174-231). */
+size_t nvdr_rasterize_scratch_bytes_pool(int N, int max_tri, int H, int W, long long pool_per_image);
+size_t nvdr_rasterize_pool_peak_offset(int N, int max_tri, int H, int W, long long pool_per_image);
+
 /* instance_mode != 0: pos [N,V,4]; else pos [V,4] and ranges [N,2] (device copy of the
  * reference's CPU `ranges` tensor).  peel_depth: previous layer's depth surface
  * [N,Hpad,Wpad] u32 or NULL (NULL = no peel test, i.e. peeling_idx <= 0).  depth_out:
@@ -80,7 +97,7 @@ size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W);
 int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
                        int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                        const uint32_t* peel_depth, uint32_t* depth_out,
-                       void* scratch, size_t scratch_bytes, int scratch_clean,
+                       void* scratch, size_t scratch_bytes, int scratch_clean, long long pool_per_image,
                        float* out, float* out_db, nvdrStream_t stream);
 
 /* grad_pos (shape of pos) must be zero-filled by the caller (reference: zeros_like,

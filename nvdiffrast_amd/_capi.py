@@ -17,8 +17,9 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
-ABI_VERSION = 3            # include/nvdr_hip.h; 2: nvdr_rasterize_fwd takes scratch_clean; 3: options + log
-OPT_LOG_LEVEL, OPT_CUBE_CORNER_FIX = 0, 1
+ABI_VERSION = 4            # include/nvdr_hip.h; 2: scratch_clean; 3: options + log; 4: caller-chosen clip pool
+OPT_LOG_LEVEL, OPT_CUBE_CORNER_FIX, OPT_SCRATCH_LIMIT_MB = 0, 1, 2
+c_longlong = ctypes.c_longlong
 
 SIGNATURES = {
     "nvdr_last_error": (ctypes.c_char_p, []),
@@ -30,8 +31,10 @@ SIGNATURES = {
     "nvdr_profile_reset": (None, []),
     "nvdr_profile_read": (c_int, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int), c_int]),
     "nvdr_rasterize_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "nvdr_rasterize_scratch_bytes_pool": (c_size_t, [c_int, c_int, c_int, c_int, c_longlong]),
+    "nvdr_rasterize_pool_peak_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_longlong]),
     "nvdr_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
     "nvdr_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nvdr_interpolate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

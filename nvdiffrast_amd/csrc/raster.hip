@@ -324,8 +324,12 @@ __device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0
     if (pool_slot < 0) return ns;
     if (ns == 0) { if (boxStage) *boxStage = kEmptyBox; else p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return 0; }
     emit_record(p, n, slot0, st[0], id, s_hist, stage, boxStage);
-    for (int k = 1; k < ns; k++)                             // cannot exceed slots - poolBase by construction
-        emit_record(p, n, p.poolBase + pool_slot + k - 1, st[k], id, s_hist, nullptr, nullptr);
+    // With the worst-case pool (6 per triangle) the slot can never exceed the pool; with a smaller pool chosen by
+    // the caller, sub-triangles beyond it are dropped HERE and the call is reported as short through poolPeak
+    // (the caller grows the pool and repeats the call, cf. the reference's retry, RasterImpl.cpp:174-231).
+    for (int k = 1; k < ns; k++)
+        if (pool_slot + k - 1 < p.slots - p.poolBase)
+            emit_record(p, n, p.poolBase + pool_slot + k - 1, st[k], id, s_hist, nullptr, nullptr);
     return ns;
 }
 
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
 // The kernel is the last reader of k_setup's counters and zeroes them on the way out: the control
 // block is left as the next rasterize call needs it (no memset launch in front of every call).
 __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int* __restrict__ binHi, int* __restrict__ binLoInv,
-                                                int* __restrict__ poolCount, int* __restrict__ poolFinal, int N,
+                                                int* __restrict__ poolCount, int* __restrict__ poolFinal, int* __restrict__ poolPeak, int N,
                                                 int4* __restrict__ order, int totalBins)
 {
     __shared__ int s_bucket[32];
@@ -498,7 +502,11 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         binCount[i] = 0; binHi[i] = 0; binLoInv[i] = 0;   // this thread was the bin's only reader in this pass
     }
     if (blockIdx.x == 0)
-        for (int n = threadIdx.x; n < N; n += 1024) { poolFinal[n] = poolCount[n]; poolCount[n] = 0; }
+        for (int n = threadIdx.x; n < N; n += 1024) {
+            const int need = poolCount[n];
+            poolFinal[n] = need; poolCount[n] = 0;
+            if (poolPeak) atomicMax(poolPeak, need);             // largest per-image demand of this call (all viewport tiles)
+        }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1100,9 +1108,10 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 // Host side
 // ---------------------------------------------------------------------------------
 
-struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, order, total; int slots, poolBase, maxBins; };
+struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, poolPeak, order, total; int slots, poolBase, maxBins, poolSlots; };
 
-static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
+// pool_per_image: slots per image for the clipper's extra sub-triangles; < 0 or >= 6 * max_tri = the worst case.
+static ScratchLayout scratch_layout(int N, int max_tri, int H, int W, long long pool_per_image = -1)
 {
     ScratchLayout L;
     {   // bins of the largest viewport tile (torch_rasterize.cpp:99-102 tiling)
@@ -1112,7 +1121,9 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
         L.maxBins = ((tsx + 63) / 64) * ((tsy + 63) / 64);
     }
     L.poolBase = (max_tri + 3) & ~3;                       // pool slots start 16-byte aligned in the AABB array
-    L.slots = L.poolBase + (((kSubPerTri - 1) * max_tri + 3) & ~3);
+    const long long worst = (long long)(kSubPerTri - 1) * max_tri;
+    L.poolSlots = (int)((pool_per_image < 0 || pool_per_image > worst) ? worst : pool_per_image);
+    L.slots = L.poolBase + ((L.poolSlots + 3) & ~3);
     L.rec   = 0;
     L.bbox  = align_up(L.rec + (size_t)N * L.slots * 64, 256);
     L.pool  = align_up(L.bbox + (size_t)N * L.slots * 4, 256);
@@ -1123,7 +1134,8 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W)
     L.binLoInv = L.binHi + (size_t)N * L.maxBins * 4;
     L.ctlEnd = L.binLoInv + (size_t)N * L.maxBins * 4;
     L.poolFinal = align_up(L.ctlEnd, 256);
-    L.order = align_up(L.poolFinal + (size_t)N * 4, 256);
+    L.poolPeak = align_up(L.poolFinal + (size_t)N * 4, 256);
+    L.order = align_up(L.poolPeak + 4, 256);
     L.total = align_up(L.order + (size_t)N * L.maxBins * 16, 256);
     return L;
 }
@@ -1138,10 +1150,22 @@ extern "C" size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W)
     return scratch_layout(N, max_tri, H, W).total;
 }
 
+extern "C" size_t nvdr_rasterize_scratch_bytes_pool(int N, int max_tri, int H, int W, long long pool_per_image)
+{
+    if (N <= 0 || max_tri <= 0 || H <= 0 || W <= 0) return 0;
+    return scratch_layout(N, max_tri, H, W, pool_per_image).total;
+}
+
+extern "C" size_t nvdr_rasterize_pool_peak_offset(int N, int max_tri, int H, int W, long long pool_per_image)
+{
+    if (N <= 0 || max_tri <= 0 || H <= 0 || W <= 0) return 0;
+    return scratch_layout(N, max_tri, H, W, pool_per_image).poolPeak;
+}
+
 extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
                                   int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                                   const uint32_t* peel_depth, uint32_t* depth_out,
-                                  void* scratch, size_t scratch_bytes, int scratch_clean,
+                                  void* scratch, size_t scratch_bytes, int scratch_clean, long long pool_per_image,
                                   float* out, float* out_db, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1154,7 +1178,8 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
     NVDR_REQUIRE(!((uintptr_t)out_db & 15), "out_db output tensor not aligned to float4");
     NVDR_REQUIRE(!((uintptr_t)scratch & 255), "scratch must be 256-byte aligned");
     NVDR_REQUIRE((long long)max_tri * kSubPerTri < (1ll << 31) / 4, "subtriangle count overflow");
-    ScratchLayout L = scratch_layout(N, max_tri, H, W);
+    ScratchLayout L = scratch_layout(N, max_tri, H, W, pool_per_image);
+    const bool shortPool = L.poolSlots < (kSubPerTri - 1) * max_tri;   // overflow possible: the caller reads poolPeak back
     if (scratch_bytes < L.total) { set_error("rasterize_fwd: scratch too small (%zu < %zu)", scratch_bytes, L.total); return NVDR_ERR_SCRATCH; }
 
     char* sb = (char*)scratch;
@@ -1195,6 +1220,8 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         sp.binCount = binCount; sp.binsX = binsX; sp.binsY = binsY;
         sp.binHi = binHi; sp.binLoInv = binLoInv;
         int* poolFinal = (int*)(sb + L.poolFinal);
+        int* poolPeak = shortPool ? (int*)(sb + L.poolPeak) : nullptr;
+        if (shortPool && tx == 0 && ty == 0) NVDR_HIP_CHECK(hipMemsetAsync(poolPeak, 0, 4, stream));
         const int bpi = (max_tri + 255) / 256;
         // Every call leaves the control block zeroed (k_order); it is cleared here only when the caller
         // cannot vouch for that (first use of the buffer, another layout, a failed call).
@@ -1207,7 +1234,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         NVDR_LAUNCH_CHECK();
         {
             ProfileScope ps("raster_order", stream);
-            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, N, order, totalBins);
+            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, poolPeak, N, order, totalBins);
         }
         NVDR_LAUNCH_CHECK();
 

@@ -115,6 +115,7 @@ class RasterizeCRStateWrapper:
         self.captured = False    # some call of this context was recorded into a hipGraph
         self.retired = []        # scratch buffers that recorded graphs still point to
         self.reported_bytes = 0
+        self.pools = {}          # (N, max_tri) -> clip-pool slots per image that the last call in growing mode needed
         self.depth = None        # current depth surface  [N,Hp,Wp] int32 (u32 bits)
         self.peel = None         # previous layer's depth surface
 
@@ -147,6 +148,15 @@ class RasterizeCRStateWrapper:
 
     def mark_clean(self, layout):
         self.clean_layout = layout
+
+    def pool_hint(self, n, max_tri):
+        """Clip-pool slots per image to start with in growing mode: what this shape needed last time, else the worst
+        case of 4096 triangles (small meshes are covered completely) or a quarter slot per triangle."""
+        return self.pools.get((n, max_tri), min(6 * max_tri, max(6 * 4096, max_tri // 4)))
+
+    def grow_pool(self, n, max_tri, need):
+        self.pools[(n, max_tri)] = min(6 * max_tri, need + need // 4 + 1024)
+        return self.pools[(n, max_tri)]
 
     def depth_surfaces(self, shape, device, swap):
         """Returns (peel_in or None, depth_out); mirrors swapDepthAndPeel (RasterImpl.cpp:123-130)."""
@@ -194,20 +204,37 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     with torch.cuda.device(dev):
         out = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         out_db = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
-        nbytes = lib.nvdr_rasterize_scratch_bytes(depth, max_tri, height, width)
-        layout = (depth, max_tri, height, width)
-        scratch, clean = state.get_scratch(nbytes, dev, layout)
-
         # Depth surfaces exist only while peeling (peeling_idx >= 0); layer k > 0 reads layer k-1's.
         peel_in = depth_out = None
         if peeling_idx >= 0:
             peel_in, depth_out = state.depth_surfaces((depth, _pad8(height), _pad8(width)), dev, swap=peeling_idx > 0)
 
-        rc = lib.nvdr_rasterize_fwd(pos.data_ptr(), tri.data_ptr(), _capi.ptr(ranges_dev),
-                                    int(instance_mode), depth, V, T, max_tri, height, width,
-                                    _capi.ptr(peel_in), _capi.ptr(depth_out),
-                                    scratch.data_ptr(), scratch.numel(), int(clean),
-                                    out.data_ptr(), out_db.data_ptr(), _stream(dev))
+        # Scratch policy (include/nvdr_hip.h, NVDR_OPT_SCRATCH_LIMIT_MB): the worst case while it is affordable -- no
+        # overflow possible, no host synchronisation, hipGraph-capturable -- otherwise a clip pool that grows on demand.
+        worst = lib.nvdr_rasterize_scratch_bytes(depth, max_tri, height, width)
+        adaptive = worst > (int(lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB)) << 20)
+        pool = state.pool_hint(depth, max_tri) if adaptive else -1
+        if adaptive and _is_capturing(dev):
+            _fail(fn, "this call needs %d MB of worst-case rasterizer scratch, above the NVDR_OPT_SCRATCH_LIMIT_MB limit; the "
+                      "growing clip pool used instead reads a counter back after each call and cannot be captured into a "
+                      "graph (raise the limit to capture)" % (worst >> 20))
+        while True:
+            nbytes = lib.nvdr_rasterize_scratch_bytes_pool(depth, max_tri, height, width, pool)
+            layout = (depth, max_tri, height, width, pool)
+            scratch, clean = state.get_scratch(nbytes, dev, layout)
+            rc = lib.nvdr_rasterize_fwd(pos.data_ptr(), tri.data_ptr(), _capi.ptr(ranges_dev),
+                                        int(instance_mode), depth, V, T, max_tri, height, width,
+                                        _capi.ptr(peel_in), _capi.ptr(depth_out),
+                                        scratch.data_ptr(), scratch.numel(), int(clean), pool,
+                                        out.data_ptr(), out_db.data_ptr(), _stream(dev))
+            if rc != 0 or not adaptive:
+                break
+            off = lib.nvdr_rasterize_pool_peak_offset(depth, max_tri, height, width, pool)
+            need = int(scratch[off:off + 4].view(torch.int32).item())        # the one host synchronisation of this mode
+            if need <= pool:
+                break
+            pool = state.grow_pool(depth, max_tri, need)
+            _log_info("Clip pool grown to %d sub-triangle slots per image" % pool)
     _capi.check(rc, fn)
     state.mark_clean(layout)
     return out, out_db

@@ -51,7 +51,7 @@ def test_scratch_query_is_pure_host_code(lib):
 
 def test_bad_arguments_are_rejected_before_any_launch(lib):
     # Null pointers / empty shapes must come back as NVDR_ERR_ARG with a message, not crash.
-    rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, 0, None, None, None)
+    rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, 0, -1, None, None, None)
     assert rc == 1
     assert b"null pointer" in lib.nvdr_last_error()
     rc = lib.nvdr_interpolate_fwd(None, None, None, None, 1, 1, 1, 3, 4, 1, 8, 8, 0, None, 0, None, None, None)
@@ -272,3 +272,23 @@ def test_operator_layer_is_not_a_copy_of_the_reference_file():
     trivial = {"pass", "else:", "return None", "@staticmethod", "import torch", "import warnings", "import numpy as np"}
     same = [l for l in ours if l in theirs and l not in trivial]
     assert len(same) < len(ours) / 3, (len(same), len(ours))
+
+
+def test_scratch_sizes_of_the_two_policies():
+    """Worst case = 7 record slots per triangle; a caller-chosen clip pool shrinks it (one million
+    triangles at batch 64 needed ~30 GB).  Pure host arithmetic, no GPU."""
+    from nvdiffrast_amd import _capi
+    from nvdiffrast_amd.torch._plugin import RasterizeCRStateWrapper
+    lib = _capi.load()
+    N, T = 64, 1000000
+    worst = lib.nvdr_rasterize_scratch_bytes(N, T, 512, 512)
+    assert worst == lib.nvdr_rasterize_scratch_bytes_pool(N, T, 512, 512, -1) == lib.nvdr_rasterize_scratch_bytes_pool(N, T, 512, 512, 6 * T)
+    assert 29e9 < worst < 32e9
+    st = RasterizeCRStateWrapper(0)
+    pool = st.pool_hint(N, T)
+    small = lib.nvdr_rasterize_scratch_bytes_pool(N, T, 512, 512, pool)
+    assert pool == T // 4 and 5.0e9 < small < 5.8e9
+    assert lib.nvdr_rasterize_pool_peak_offset(N, T, 512, 512, pool) + 4 <= small
+    assert st.pool_hint(2, 100) == 600                                   # small meshes: the complete worst case
+    assert st.grow_pool(N, T, 400000) == 501024 and st.pool_hint(N, T) == 501024
+    assert lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB) == 1024

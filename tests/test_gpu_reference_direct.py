@@ -173,3 +173,39 @@ def test_graphs_and_eager_calls_with_mixed_layouts_on_one_context(dr, oracle):
             assert (static[k][1].cpu().numpy()[..., 3] != scenes[k][2][..., 3]).sum() == 0
             r3, _ = dr.rasterize(ctx, pos3, tri3, res3)       # eager, other layout, larger scratch
             assert (r3.cpu().numpy()[..., 3] != ro3[..., 3]).sum() == 0
+
+
+def test_growing_clip_pool_gives_the_same_image(dr, oracle, capfd):
+    """NVDR_OPT_SCRATCH_LIMIT_MB = 0 forces the growing-pool scratch policy (what meshes of millions of triangles get);
+    a scene in which every triangle crosses frustum planes overflows the initial pool, the glue reads the demand back,
+    grows the pool and repeats the call: ids must equal the oracle's (and the reference's) like in worst-case mode."""
+    from nvdiffrast_amd import _capi
+    from nvdiffrast_amd.torch import _plugin
+    rng = np.random.default_rng(12)
+    T = 9000
+    pos = rng.normal(size=(2, 3 * T, 4)).astype(np.float32) * np.array([3.0, 3.0, 1.5, 1.0], np.float32)
+    pos[..., 3] = rng.uniform(0.05, 1.5, size=pos.shape[:2])
+    tri = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    ro, _ = oracle.rasterize(pos, tri, (96, 128))
+    lib = _capi.load()
+    old = lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB)
+    lib.nvdr_set_option(_capi.OPT_SCRATCH_LIMIT_MB, 0)
+    _plugin.set_log_level(0)
+    try:
+        ctx = dr.RasterizeCudaContext()
+        ctx.cpp_wrapper.pools[(2, T)] = 64                       # start far too small
+        r, _ = dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))
+        assert (r.cpu().numpy()[..., 3] != ro[..., 3]).sum() == 0
+        grown = ctx.cpp_wrapper.pools[(2, T)]
+        assert 64 < grown <= 6 * T
+        assert "Clip pool grown" in capfd.readouterr().err
+        r2, _ = dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))    # second call: the remembered size fits at once
+        assert torch.equal(r, r2) and ctx.cpp_wrapper.pools[(2, T)] == grown
+        assert "Clip pool grown" not in capfd.readouterr().err
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))
+    finally:
+        lib.nvdr_set_option(_capi.OPT_SCRATCH_LIMIT_MB, old)
+        _plugin.set_log_level(1)
