@@ -202,10 +202,11 @@ def test_growing_clip_pool_gives_the_same_image(dr, oracle, capfd):
         r2, _ = dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))    # second call: the remembered size fits at once
         assert torch.equal(r, r2) and ctx.cpp_wrapper.pools[(2, T)] == grown
         assert "Clip pool grown" not in capfd.readouterr().err
+        t_pos, t_tri = _t(pos), _t(tri)
         with pytest.raises(RuntimeError, match="cannot be captured"):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))
+                dr.rasterize(ctx, t_pos, t_tri, (96, 128))
     finally:
         lib.nvdr_set_option(_capi.OPT_SCRATCH_LIMIT_MB, old)
         _plugin.set_log_level(1)
