@@ -669,8 +669,60 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         return RunScan(RunScan::FromHead{}, !same, true);
     };
 
+    // ---- phase B, uniform waves -------------------------------------------------------------------
+    // A wave whose 64 pixels all carry the SAME texture coordinate with a ZERO pixel footprint -- the background of a
+    // rendered image, which interpolate() fills with uv = 0, uv_da = 0 -- samples level 0 bilinearly at one place:
+    // flevel = clamp(log2(0) [+ bias]) = 0 and the level gradient vanishes (:477-585), so g_uv_da = g_bias = 0 and
+    // every lane's contribution to the four texels is weight * dy.  Such a wave sums dy over its lanes and lets ONE
+    // lane claim the patch and add the four totals, instead of 64 lanes probing the same hash key (a 64-way
+    // same-address LDS atomic per probe) and carrying the whole general path.  Exact up to the summation order.
+    bool uniformWave = false;
+    if (!CUBE && !direct && !(p.dbg & (1024 | 4096)) && (FILTER == TEX_LINEAR || ((FILTER == TEX_LMN || FILTER == TEX_LML) && !BIAS_ONLY))) {
+        if (__ballot(active) == ~0ull) {
+            const float2 t = ((const float2*)p.uv)[pidx];
+            const int ux = __float_as_int(t.x), uy = __float_as_int(t.y);
+            bool same = (ux == __builtin_amdgcn_readfirstlane(ux)) & (uy == __builtin_amdgcn_readfirstlane(uy));
+            if (FILTER != TEX_LINEAR) {
+                const float4 d = ((const float4*)p.uvDA)[pidx];
+                same &= (d.x == 0.f) & (d.y == 0.f) & (d.z == 0.f) & (d.w == 0.f);
+                if (p.bias) same &= !(fabsf(p.bias[pidx]) == INFINITY);          // -inf + inf would be NaN, not -inf
+            }
+            uniformWave = __ballot(same) == ~0ull;
+        }
+    }
+    if (uniformWave) {
+        const int lane = threadIdx.x & 63;
+        const float2 t = ((const float2*)p.uv)[pidx];
+        const Quad q0 = tex_index_linear(p, t.x, t.y, tz, 0);
+        const float* pIn0 = p.tex[0];
+        const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
+        const float tw0[4] = {w000, w010, w001, w011};
+        const float sclu0 = (float)p.texW, sclv0 = (float)p.texH;
+        int sl0[4] = {-1, -1, -1, -1};
+        if (lane == 63) slots_of(q0, 0, sl0);
+        float gu = 0.f, gv = 0.f;
+        for (int c = 0; c < C; c++) {
+            const float d = pDy[c];
+            const float tot = wave_sum_to_last(d);                       // valid in lane 63
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const float v = tw0[k] * tot; scatter(sl0[k], c, v); spill(sl0[k], 0, q0.tc[k], c, v); }
+            }
+            float a[4];
+            fetch_quad(pIn0, q0, C, c, a);
+            const float ad = (a[3] + a[0] - a[1] - a[2]);
+            gu += d * ((a[1] - a[0]) + q0.fv * ad) * sclu0;
+            gv += d * ((a[2] - a[0]) + q0.fu * ad) * sclv0;
+        }
+        ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+        if (FILTER == TEX_LML) {
+            if (p.gradBias) p.gradBias[pidx] = 0.f;
+            if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     // ---- phase B --------------------------------------------------------------------------------
-    if (active) {
+    if (active && !uniformWave) {
         float3 uv3 = make_float3(0.f, 0.f, 0.f);
         if (CUBE) { const float* q = p.uv + pidx * 3; uv3 = make_float3(q[0], q[1], q[2]); }
         else { const float2 t = ((const float2*)p.uv)[pidx]; uv3 = make_float3(t.x, t.y, 0.f); }

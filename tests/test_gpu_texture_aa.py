@@ -284,3 +284,36 @@ def test_full_chain_config3(dr, oracle):
     _close(t_tex.grad.cpu().numpy(), tg["tex"], _tol(tg["tex"]) * 4, 2e-3)
     _close(uvattr.grad.cpu().numpy(), g_uvattr, _tol(g_uvattr) * 8, 5e-3)
     _close(pos.grad.cpu().numpy(), g_pos, _tol(g_pos) * 8, 5e-3)
+
+
+@pytest.mark.parametrize("bm", ["wrap", "clamp", "zero"])
+@pytest.mark.parametrize("fm", ["linear", "linear-mipmap-nearest", "linear-mipmap-linear"])
+def test_texture_backward_on_constant_uv_regions(dr, oracle, fm, bm):
+    """Background of a render: interpolate() gives uv = 0 and uv_da = 0 there, every pixel of a wave hits the same four
+    texels.  Whole waves of such pixels take k_tex_grad's uniform-wave path; mixed waves (region borders, a second
+    constant value, a non-zero footprint, zero upstream gradients) must fall back to the general one."""
+    rng = np.random.default_rng(321)
+    N, H, W, C = 2, 48, 80, 3
+    tex = rng.uniform(size=(1, 32, 64, C)).astype(np.float32)
+    uv = rng.uniform(-0.2, 1.2, size=(N, H, W, 2)).astype(np.float32)
+    mip = "mipmap" in fm
+    uv_da = (rng.normal(size=(N, H, W, 4)) * 0.05).astype(np.float32)
+    uv[0, :, :48] = 0.0; uv_da[0, :, :48] = 0.0                    # background, texel corner (0,0): all four wrap taps
+    uv[1, 8:40, 16:64] = np.array([0.37, 0.61], np.float32); uv_da[1, 8:40, 16:64] = 0.0   # a flat region elsewhere
+    uv[1, :8, :32] = 0.0                                            # constant uv but a NON-zero footprint: general path
+    bias = rng.uniform(-0.5, 0.5, size=(N, H, W)).astype(np.float32) if fm == "linear-mipmap-linear" else None
+    dy = rng.normal(size=(N, H, W, C)).astype(np.float32)
+    dy[0, 16:24, :16] = 0.0                                         # zero upstream gradients inside the background
+    kw = dict(filter_mode=fm, boundary_mode=bm)
+    t_tex = _t(tex).requires_grad_(True)
+    t_uv = _t(uv).requires_grad_(True)
+    t_da = _t(uv_da).requires_grad_(True) if mip else None
+    t_bias = _t(bias).requires_grad_(True) if bias is not None else None
+    out = dr.texture(t_tex, t_uv, t_da, t_bias, **kw)
+    out.backward(_t(dy))
+    g = oracle.texture_grad(tex, uv, dy, uv_da if mip else None, bias, **kw)
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), 2e-3)
+    _close(t_uv.grad.cpu().numpy(), g["uv"], _tol(g["uv"]) * 4, 2e-3)
+    if fm == "linear-mipmap-linear":
+        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]) * 4, 2e-3)
+        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]) * 4, 2e-3)

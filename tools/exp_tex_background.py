@@ -33,3 +33,12 @@ print('coverage', float(mask.mean()))
 run(G, 'dense G')
 run(G * mask, 'G masked to covered pixels')
 run(G * (1 - mask), 'G only on background')
+# hypothesis check: is the background's cost the cross-block contention on the same 4 texels?  Give every 16x16 block
+# its own constant uv (still uniform inside each wave) and compare.
+by, bx = torch.meshgrid(torch.arange(R, device=dev) // 16, torch.arange(R, device=dev) // 16, indexing='ij')
+uv_blk = torch.stack([(bx.float() * 7.0 + 0.5) / 2048.0, (by.float() * 5.0 + 0.5) / 2048.0], -1)[None].expand(N, -1, -1, -1)
+bg = (1 - mask)
+uv2 = (uv.detach() * mask + uv_blk * bg).contiguous().requires_grad_(True)
+uv_saved = uv
+uv = uv2
+run(G * bg, 'G only on background, per-block distinct uv')
