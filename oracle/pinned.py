@@ -102,6 +102,28 @@ class PinnedOracle:
         self._close(op, "rast(u,v,z/w)", ro[same][:, :3], r[same][:, :3], atol=FWD_ATOL)
         self._close(op, "rast_db", dbo[same], db[same], rtol=FWD_ATOL)
 
+    def rasterize_ids(self, pos, tri, resolution, ranges=None, peel_depth=None):
+        """Integer surfaces (ids, U32 depth): identical to the surfaces of the reference's CudaRaster context --
+        every covered pixel's depth VALUE, not only the winning triangle."""
+        ids, depth = self._o.rasterize_ids(pos, tri, resolution, ranges=ranges, peel_depth=peel_depth)
+        if self.enabled and peel_depth is None and self._small_enough(ids):
+            rid, rdepth = _ref.rasterize_surfaces(pos, tri, resolution, ranges)
+            bad = ids != rid
+            if bad.any() and self.have_nofma:
+                nid, ndepth = _ref.rasterize_surfaces(pos, tri, resolution, ranges, variant="nofma")
+                rid = np.where(bad & (ids == nid), nid, rid); rdepth = np.where(bad & (ids == nid), ndepth, rdepth)
+                bad = ids != rid
+            if bad.any():
+                raise PinMismatch("rasterize_ids: %d triangle ids differ from the reference" % int(bad.sum()))
+            cov = ids > 0
+            dbad = cov & (depth != rdepth)
+            self._note("rasterize_ids", 0.0)
+            if dbad.any():
+                i = tuple(np.argwhere(dbad)[0])
+                raise PinMismatch("rasterize_ids: %d of %d covered pixels differ in their U32 depth (first at %s: oracle %d, reference %d)"
+                                  % (int(dbad.sum()), int(cov.sum()), i, int(depth[i]), int(rdepth[i])))
+        return ids, depth
+
     def rasterize_layers(self, pos, tri, resolution, num_layers, ranges=None):
         """Depth peeling: list of (rast, rast_db, depth) from the oracle's explicit-peel-surface form, each layer
         pinned to what the reference's context produces for peeling_idx = layer (ops.py:141-204)."""

@@ -289,6 +289,20 @@ def rasterize(pos, tri, resolution, ranges=None, variant="fma", ctx=None):
     return P.rasterize_fwd_cuda(ctx, pos, tri, resolution, _EMPTY_RANGES if ranges is None else ranges, -1)
 
 
+def rasterize_surfaces(pos, tri, resolution, ranges=None, variant="fma"):
+    """-> (ids u32 [N,Hp,Wp] = triangle id + 1, depth u32 [N,Hp,Wp]): the rasterizer's own integer surfaces
+    (what oracle.rasterize_ids restates), read back from the CudaRaster context after a forward call."""
+    P = plugin(variant)
+    ctx = P.RasterizeCRStateWrapper()
+    r, _ = P.rasterize_fwd_cuda(ctx, pos, tri, resolution, _EMPTY_RANGES if ranges is None else ranges, -1)
+    N, H, W = r.shape[:3]
+    Hp, Wp = (H + 7) & ~7, (W + 7) & ~7
+    ids = np.empty((N, Hp, Wp), np.uint32)
+    depth = np.empty((N, Hp, Wp), np.uint32)
+    P.L.nvdr_ref_ctx_surfaces(ctx.h, ctypes.c_void_p(ids.ctypes.data), ctypes.c_void_p(depth.ctypes.data), ctypes.c_size_t(ids.size))
+    return ids, depth
+
+
 def rasterize_layers(pos, tri, resolution, num_layers, ranges=None, variant="fma"):
     """Depth peeling as DepthPeeler drives it (ops.py:141-204): layer k is a forward call with peeling_idx=k
     on ONE context.  -> list of (rast, rast_db)."""

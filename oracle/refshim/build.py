@@ -69,6 +69,13 @@ def patch_util_inl(text):
     patched, n = ASM_RE.subn(sub, text)
     if "asm(" in patched:
         raise RuntimeError("an asm statement of Util.inl was not recognised")
+    # Second rewrite, same temporary copy: the three C casts `(U32)values.{x,y,z}` of setupPleq (Util.inl:188-190) convert
+    # a float depth to an unsigned integer.  CUDA compiles them to cvt.rzi.u32.f32, which SATURATES (a vertex depth
+    # that float rounding pushed just above 2^32 -- clipped vertices on the far plane -- becomes 0xFFFFFFFF); in C++
+    # the same cast is undefined out of range and x86 wraps it.  nvdr_ptx_emu.h supplies the CUDA behaviour.
+    patched, m = re.subn(r"\(U32\)values\.([xyz])", r"nvdr_cuda_cvt_rzi_u32_f32(values.\1)", patched)
+    if m != 3:
+        raise RuntimeError("expected the three float->U32 casts of setupPleq, found %d" % m)
     return '#include "nvdr_ptx_emu.h"\n' + patched, n
 
 

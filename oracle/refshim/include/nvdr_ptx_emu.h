@@ -68,6 +68,15 @@ static inline int64_t ptx_cvt_rni_s64_f32__0___1_(float a)
     if (r <= -9223372036854775808.f) return INT64_MIN;
     return (int64_t)r;
 }
+// What nvcc makes of the C cast (unsigned)f: cvt.rzi.u32.f32 -- truncation, result clamped to [0, 2^32-1], NaN -> 0
+// (PTX ISA, "cvt": integer results of float conversions are clamped to the destination range).  Used for the three
+// casts of setupPleq, see build.py.
+static inline uint32_t nvdr_cuda_cvt_rzi_u32_f32(float a)
+{
+    if (!(a > 0.f)) return 0u;
+    if (a >= 4294967296.f) return 0xffffffffu;
+    return (uint32_t)a;
+}
 // cvt.s16.u32 into a 32-bit register: low 16 bits, sign-extended.
 static inline ptx_r ptx_cvt_s16_u32__0___1_(ptx_r a) { return (ptx_r)(int32_t)(int16_t)(a & 0xffffu); }
 

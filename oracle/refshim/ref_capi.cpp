@@ -5,6 +5,7 @@
 // TEST INFRASTRUCTURE ONLY — the product never links this.
 #include <torch/extension.h>
 #include "torch_types.h"
+#include "../CudaRaster.hpp"
 
 // Prototypes exactly as torch_bindings.cpp:23-39 declares them.
 std::tuple<torch::Tensor, torch::Tensor> rasterize_fwd_cuda(RasterizeCRStateWrapper& stateWrapper, torch::Tensor pos, torch::Tensor tri, std::tuple<int, int> resolution, torch::Tensor ranges, int peeling_idx);
@@ -122,6 +123,16 @@ int nvdr_ref_rasterize_grad(const nvdr_ref_tensor* pos, const nvdr_ref_tensor* t
 { NVDR_REF_TRY( put(res_, rasterize_grad(T(pos), T(tri), T(rast), T(dy))); ) }
 int nvdr_ref_rasterize_grad_db(const nvdr_ref_tensor* pos, const nvdr_ref_tensor* tri, const nvdr_ref_tensor* rast, const nvdr_ref_tensor* dy, const nvdr_ref_tensor* ddb, Results** out)
 { NVDR_REF_TRY( put(res_, rasterize_grad_db(T(pos), T(tri), T(rast), T(dy), T(ddb))); ) }
+
+// The rasterizer's internal surfaces after the last forward call of this context: triangle id + 1 ("colour") and
+// the U32 depth, [N, Hpad, Wpad] with Hpad/Wpad = H/W rounded up to 8 (RasterImpl.cpp:87-99).  Lets tests compare the
+// integer depth surface itself, not only which triangle won.
+void nvdr_ref_ctx_surfaces(void* ctx, uint32_t* color, uint32_t* depth, size_t count)
+{
+    CR::CudaRaster* cr = ((RasterizeCRStateWrapper*)ctx)->cr;
+    if (color) memcpy(color, cr->getColorBuffer(), count * 4);
+    if (depth) memcpy(depth, cr->getDepthBuffer(), count * 4);
+}
 
 //------------------------------------------------------------------------ interpolate
 int nvdr_ref_interpolate_fwd(const nvdr_ref_tensor* attr, const nvdr_ref_tensor* rast, const nvdr_ref_tensor* tri, Results** out)

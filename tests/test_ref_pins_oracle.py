@@ -372,3 +372,26 @@ def test_lut_coverage_equals_the_integer_fill_rule(ref):
             rule |= (((ox - 16 * x) * dy - (oy - 16 * y) * dx - excl) >= 0).astype(np.uint64) << np.uint64(x + 8 * y)
     assert (rule != m[:, 0]).sum() == 0, "integer fill rule differs from the reference's LUT coverage"
     assert 0.05 < float((rule != 0).mean()) < 0.95                                    # the sample is not trivial
+
+
+def test_integer_depth_surfaces_are_identical(po):
+    """Beyond "the same triangle wins": the U32 depth of every covered pixel equals the value in the reference's depth
+    buffer (read back from its CudaRaster context) -- depth-plane setup (Util.inl:184-210), clipped sub-triangles,
+    vertex depths that float rounding pushed past 2^32 (the conversion saturates on CUDA), range mode."""
+    b = m10k_batch(2, seed=11)
+    po.rasterize_ids(b["pos"], b["tri"], (250, 333))
+    s = stress_triangles(2, T=3000, res=192, seed=3)
+    po.rasterize_ids(s["pos"], s["tri"], (192, 192))
+    rng = np.random.default_rng(5)
+    T = 600
+    pos = rng.normal(size=(2, 3 * T, 4)).astype(np.float32) * np.array([2.0, 2.0, 1.5, 1.0], np.float32)
+    pos[..., 3] = rng.uniform(-0.5, 2.0, size=pos.shape[:2])
+    po.rasterize_ids(pos, np.arange(3 * T, dtype=np.int32).reshape(T, 3), (128, 200))
+    b = m10k_batch(1, seed=4, nx=30, ny=20)
+    po.rasterize_ids(b["pos"][0], b["tri"], (96, 128), ranges=np.array([[0, 1160], [100, 500]], np.int32))
+    # the triangle the randomised test found: near- and far-clipped, one vertex depth above 2^32 after rounding
+    tri264 = np.array([[[4.076959133148193, -4.071649074554443, -4.839981555938721, 2.0703206062316895],
+                        [0.7489162087440491, 1.5174667835235596, 1.0366004705429077, 0.7550548315048218],
+                        [-0.015080906450748444, 0.00025000300956889987, 0.01805366948246956, 0.012354218401014805]]], np.float32)
+    ids, _ = po.rasterize_ids(tri264, np.array([[0, 1, 2]], np.int32), (118, 10))
+    assert (ids > 0).sum() > 500
