@@ -48,6 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_LINK_GBS = 153.0          # per direction per link; 7 links per GPU, fully connected (task statement / SURVEY 8e)
 TRIANGLES = 10000
 
 WORKLOADS = {
@@ -134,26 +135,39 @@ def main():
     ap.add_argument("--res", type=int, default=None, help="resolution (overrides the workload's; dry runs use a small one)")
     ap.add_argument("--chunks", type=int, default=None,
                     help="N > 1: the rank's items are rendered in this many chunks so that a chunk's image all-gather "
-                         "overlaps the next chunk's kernels (default 4; 1 at N = 1)")
+                         "overlaps the next chunk's kernels (default: chunks of >= 64 items, at most 4; 1 at N = 1)")
     ap.add_argument("--no-gather-images", action="store_true", help="N > 1: keep the output images sharded (no all-gather in the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-items", type=int, default=64, help="items in the CPU-oracle sample")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into one hipGraph and time replays (single GPU only; the default, and the "
                          "number the driver records, is eager launching)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the N > 1 code path (process group, broadcast, chunked all-gather, all-reduce) even with one rank: "
+                         "checks the RCCL calls on a 1-GPU box")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo + stand-in kernels: exercises the multi-rank plumbing without GPUs")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         respawn_under_launcher(args)                             # does not return
+    # The JSON line must be the only thing on stdout.  Native libraries write there too (RCCL prints a version banner from C
+    # stdio, flushed at exit, i.e. AFTER the line): everything else this process writes to fd 1 goes to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if launched and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    distributed = world > 1
+    distributed = world > 1 or args.force_collectives
     dry = args.dry_run_cpu
+    if distributed and not launched:                              # --force-collectives without a launcher: a group of one
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
 
     import torch.distributed as dist
     if dry:
@@ -182,7 +196,9 @@ def main():
     else:
         N = args.batch or wl["per_gpu"]
         total_items, first = N * world, N * rank
-    chunks = args.chunks or (4 if distributed else 1)
+    # A chunk must carry enough pixels to cover the host's launch work for it (measured: 16-item chunks at 512^2 doubled the
+    # step time, 64-item chunks cost nothing); with one chunk the gather still overlaps the backward kernels.
+    chunks = args.chunks or (max(1, min(4, N // 64)) if distributed else 1)
     chunks = max(1, min(chunks, N))
     gather = distributed and not args.no_gather_images
 
@@ -218,6 +234,7 @@ def main():
         topo = dr.antialias_construct_topology_hash(tri) if full else None
 
     bounds = [(N * c // chunks, N * (c + 1) // chunks) for c in range(chunks)]
+    mode = {"gather": gather}                                     # switched off for the second, gather-free timing below
     gathered = [None] * chunks                                    # receive buffers, reused every step
 
     def render(p):
@@ -242,7 +259,7 @@ def main():
         for c, (a, b) in enumerate(bounds):
             p = pos if chunks == 1 else pos[a:b]
             out, rast = render(p)
-            if gather:
+            if mode["gather"]:
                 # the collective runs on RCCL's own stream, ordered after this chunk's kernels; the next chunk's
                 # kernels are issued right away and overlap it
                 work, gathered[c] = gather_items_async(out.detach(), out=gathered[c])
@@ -277,23 +294,46 @@ def main():
         with torch.cuda.graph(graph):
             step()
         run = graph.replay
-    for _ in range(args.warmup):
-        run()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(warmup, steps):
+        """`steps` steps bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
+        for _ in range(warmup):
+            run()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        fence()
+        el = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    elapsed = timed(args.warmup, args.steps)
     ranks_seen = world
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         ones = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)               # every rank took part in the timed region
         ranks_seen = int(round(float(ones.item())))
         assert ranks_seen == dist.get_world_size()
+    # The image all-gather is pure xGMI traffic whose size does not depend on how fast the kernels are: report the
+    # same job without it next to `value`, and the link arithmetic, so that the two effects can be told apart.
+    collective = None
+    if gather:
+        mode["gather"] = False
+        elapsed_ng = timed(min(args.warmup, 2), args.steps)
+        mode["gather"] = True
+        img_bytes = N * RES * RES * C_out * 4
+        links = world - 1                                         # fully connected xGMI: one link per peer (0: a forced group of one)
+        collective = {
+            "image_bytes_sent_per_rank_per_step": img_bytes * links, "image_bytes_received_per_rank_per_step": img_bytes * links,
+            "xgmi_links_per_gpu_used": links, "xgmi_link_gbs": XGMI_LINK_GBS,
+            # every link carries one rank's images, all links in parallel: the floor does not shrink with more GPUs
+            "xgmi_floor_ms": round(img_bytes / (XGMI_LINK_GBS * 1e9) * 1e3, 4) if links else None,
+            "ms_per_step_without_image_gather": round(elapsed_ng / args.steps * 1e3, 4),
+            "value_without_image_gather": round(total_items * RES * RES / (elapsed_ng / args.steps) / 1e6, 1),
+        }
 
     P_rank = N * RES * RES
     P_total = total_items * RES * RES
@@ -423,6 +463,7 @@ def main():
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
             "parity": parity,
+            "collective": collective,
         }
         if dry:
             result["dry_run"] = True
@@ -434,7 +475,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -47,7 +47,7 @@ constexpr uint32_t kEmptyBox  = 0x000000FFu;             // txlo=255 > txhi=0
 constexpr int      kSubPerTri = 7;                       // clipper output: <= 9 verts -> <= 7 tris
 
 constexpr int kBinTiles   = 8;                           // bin = 8x8 tiles = 64x64 px
-constexpr int kMaxBins    = 1024;                        // (2048 / 64)^2 bins per viewport tile
+// (at most (2048 / 64)^2 = 1024 bins per viewport tile: scratch_layout sizes the per-bin arrays from the actual count)
 constexpr int kFineWaves  = 8;                           // one wave per row of eight 8x8 tiles
 constexpr int kFineThreads = kFineWaves * 64;
 constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in the pair ring)
@@ -227,11 +227,12 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     for (int by_ = y0 >> 6; by_ <= (y1 >> 6); by_++)
         for (int bx_ = x0 >> 6; bx_ <= (x1 >> 6); bx_++)
         {
+            const int nb = p.binsX * p.binsY;                         // s_hist = [3][nb]
             const int b = by_ * p.binsX + bx_;
             atomicAdd(&s_hist[b], 1);
             if (slot < p.poolBase) {                                  // index range of the bin's direct slots
-                atomicMax(&s_hist[kMaxBins + b], slot + 1);
-                atomicMax(&s_hist[2 * kMaxBins + b], 0x7FFFFFFF - slot);
+                atomicMax(&s_hist[nb + b], slot + 1);
+                atomicMax(&s_hist[2 * nb + b], 0x7FFFFFFF - slot);
             }
         }
 
@@ -256,62 +257,69 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     if (boxStage) *boxStage = box; else p.bbox[so] = box;         // direct slots: AABBs leave as whole rows too (k_setup)
 }
 
-// Util.inl:101-130.
-__device__ int clip_poly_plane(float* out, const float* in, int n_in, float f0, float f1, float f2)
+// Workspace of the clipper: the polygon's vertices as barycentric pairs, two buffers of 9 x 2 floats per lane
+// (Sutherland-Hodgman ping-pong), in LDS and word-major -- word w of a lane at ws[w * kClipLanes] -- so that
+// lanes hit distinct banks.  (As private arrays these were dynamically indexed scratch: ~100 dependent memory
+// round trips per clipped triangle.)  112 lanes x 36 words = 16128 B: fits the 16 KiB record stage it reuses.
+constexpr int kClipLanes = 112;
+#define NVDR_CW(off, i) ws[((off) + (i)) * kClipLanes]
+
+// Util.inl:101-130: clips the polygon at word offset inOff against f0 + f1*b0 + f2*b1 >= 0 into outOff.
+__device__ __forceinline__ int clip_poly_plane(float* ws, int outOff, int inOff, int n_in, float f0, float f1, float f2)
 {
 #pragma clang fp contract(off)
     int n_out = 0;
     if (n_in >= 3) {
-        int ai = (n_in - 1) * 2;
-        float av = __fmaf_rn(f2, in[ai + 1], __fmaf_rn(f1, in[ai + 0], f0));
+        const int ai = (n_in - 1) * 2;
+        float ax = NVDR_CW(inOff, ai), ay = NVDR_CW(inOff, ai + 1);
+        float av = __fmaf_rn(f2, ay, __fmaf_rn(f1, ax, f0));
+#pragma unroll 1
         for (int bi = 0; bi < n_in * 2; bi += 2) {
-            float bv = __fmaf_rn(f2, in[bi + 1], __fmaf_rn(f1, in[bi + 0], f0));
+            const float bx = NVDR_CW(inOff, bi), by = NVDR_CW(inOff, bi + 1);
+            const float bv = __fmaf_rn(f2, by, __fmaf_rn(f1, bx, f0));
             if (av * bv < 0.0f) {
-                float bc = av / (av - bv);
-                float ac = 1.0f - bc;
-                out[n_out + 0] = __fmaf_rn(in[ai + 0], ac, in[bi + 0] * bc);
-                out[n_out + 1] = __fmaf_rn(in[ai + 1], ac, in[bi + 1] * bc);
+                const float bc = av / (av - bv);
+                const float ac = 1.0f - bc;
+                NVDR_CW(outOff, n_out + 0) = __fmaf_rn(ax, ac, bx * bc);
+                NVDR_CW(outOff, n_out + 1) = __fmaf_rn(ay, ac, by * bc);
                 n_out += 2;
             }
             if (bv >= 0.0f) {
-                out[n_out + 0] = in[bi + 0];
-                out[n_out + 1] = in[bi + 1];
+                NVDR_CW(outOff, n_out + 0) = bx;
+                NVDR_CW(outOff, n_out + 1) = by;
                 n_out += 2;
             }
-            ai = bi;
-            av = bv;
+            ax = bx; ay = by; av = bv;
         }
     }
     return n_out >> 1;
 }
 
-// Slow path, TriangleSetup.inl:355-434 + Util.inl:134-160.  Kept out of line so the common
-// path stays small.
-// pool_slot < 0: only count the surviving sub-triangles (returned); otherwise emit them, the first into
-// slot0 and the rest into pool slots pool_slot, pool_slot + 1, ... (reserved by the caller).
-__device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0, const float (*v)[4], int id, int* s_hist, uint4* stage, uint32_t* boxStage, int pool_slot)
+// Slow path, TriangleSetup.inl:355-434 + Util.inl:134-160: clip against the frustum in barycentric space, fan the
+// polygon, set up every sub-triangle.  Returns the number of survivors (at most 7), left in st[].
+__device__ __forceinline__ int clip_prepare(const SetupParams& p, const float (*v)[4], float* ws, SubTri* st)
 {
 #pragma clang fp contract(off)
-    float d1[4], d2[4], bary[18], tmp[18];
+    float d1[4], d2[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) { d1[c] = v[1][c] - v[0][c]; d2[c] = v[2][c] - v[0][c]; }
     int num = 3;
-    bary[0] = 0.f; bary[1] = 0.f; bary[2] = 1.f; bary[3] = 0.f; bary[4] = 0.f; bary[5] = 1.f;
+    NVDR_CW(0, 0) = 0.f; NVDR_CW(0, 1) = 0.f; NVDR_CW(0, 2) = 1.f; NVDR_CW(0, 3) = 0.f; NVDR_CW(0, 4) = 0.f; NVDR_CW(0, 5) = 1.f;
+#pragma unroll
     for (int ax = 0; ax < 3; ax++) {
         if ((v[0][3] < fabsf(v[0][ax])) || (v[1][3] < fabsf(v[1][ax])) || (v[2][3] < fabsf(v[2][ax]))) {
-            num = clip_poly_plane(tmp, bary, num, v[0][3] + v[0][ax], d1[3] + d1[ax], d2[3] + d2[ax]);
-            num = clip_poly_plane(bary, tmp, num, v[0][3] - v[0][ax], d1[3] - d1[ax], d2[3] - d2[ax]);
+            num = clip_poly_plane(ws, 18, 0, num, v[0][3] + v[0][ax], d1[3] + d1[ax], d2[3] + d2[ax]);
+            num = clip_poly_plane(ws, 0, 18, num, v[0][3] - v[0][ax], d1[3] - d1[ax], d2[3] - d2[ax]);
         }
     }
-
-    // First pass: set up the fan, remember survivors (at most 7).
-    SubTri st[kSubPerTri];
     int ns = 0;
     float c0[4], cp[4], cc[4];
+#pragma unroll 1
     for (int i = 0; i < num; i++) {
+        const float b0 = NVDR_CW(0, i * 2), b1 = NVDR_CW(0, i * 2 + 1);
 #pragma unroll
         for (int c = 0; c < 4; c++)
-            cc[c] = __fmaf_rn(d2[c], bary[i * 2 + 1], __fmaf_rn(d1[c], bary[i * 2 + 0], v[0][c]));
+            cc[c] = __fmaf_rn(d2[c], b1, __fmaf_rn(d1[c], b0, v[0][c]));
         if (i == 0) { for (int c = 0; c < 4; c++) c0[c] = cc[c]; }
         else if (i >= 2) {
             float t[3][4];
@@ -320,42 +328,53 @@ __device__ __noinline__ int setup_clipped(const SetupParams& p, int n, int slot0
         }
         for (int c = 0; c < 4; c++) cp[c] = cc[c];
     }
+    return ns;
+}
 
-    if (pool_slot < 0) return ns;
-    if (ns == 0) { if (boxStage) *boxStage = kEmptyBox; else p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return 0; }
-    emit_record(p, n, slot0, st[0], id, s_hist, stage, boxStage);
+// Emits the survivors: the first into the triangle's own slot, the others into pool slots pool_slot, pool_slot + 1,
+// ... (reserved by the caller), all in place.
+__device__ __forceinline__ void clip_emit(const SetupParams& p, int n, int slot0, const SubTri* st, int ns, int id, int* s_hist, int pool_slot)
+{
+    if (ns == 0) { p.bbox[(size_t)n * p.slots + slot0] = kEmptyBox; return; }
+    emit_record(p, n, slot0, st[0], id, s_hist, nullptr, nullptr);
     // With the worst-case pool (6 per triangle) the slot can never exceed the pool; with a smaller pool chosen by
     // the caller, sub-triangles beyond it are dropped HERE and the call is reported as short through poolPeak
     // (the caller grows the pool and repeats the call, cf. the reference's retry, RasterImpl.cpp:174-231).
     for (int k = 1; k < ns; k++)
         if (pool_slot + k - 1 < p.slots - p.poolBase)
             emit_record(p, n, p.poolBase + pool_slot + k - 1, st[k], id, s_hist, nullptr, nullptr);
-    return ns;
 }
 
-// `clipq` != nullptr: triangles that need the clipper are only queued (their block processes them
-// densely afterwards, see k_setup).  `clipq` == nullptr: run the clipper for triangle i -- counting the
-// sub-triangles when pool_slot < 0, emitting them otherwise.  Returns the sub-triangle count.
-__device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage, uint32_t* boxStage, int* clipq, int* clipn, int pool_slot = -1)
+// Vertices of triangle slot i of image n after the viewport-tile transform (TriangleSetup.inl:196-267).
+// Returns the triangle id + 1, or 0 when the slot holds no valid triangle.
+__device__ __forceinline__ int fetch_tri(const SetupParams& p, int n, int i, float (*v)[4])
 {
 #pragma clang fp contract(off)
-    int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
+    const int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
     if (i >= cnt) return 0;
-    size_t so = (size_t)n * p.slots + i;
-    // The slot's AABB: staged in LDS for the block's own (direct) slots, in place otherwise.
-    auto empty_box = [&]() { if (boxStage) *boxStage = kEmptyBox; else p.bbox[so] = kEmptyBox; };
-    int t = i + (p.instance ? 0 : p.ranges[2 * n]);
-    if ((uint32_t)t >= (uint32_t)p.T) { empty_box(); return 0; }                       // :228-233
-    uint32_t i0 = (uint32_t)p.tri[t * 3 + 0], i1 = (uint32_t)p.tri[t * 3 + 1], i2 = (uint32_t)p.tri[t * 3 + 2];
-    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) { empty_box(); return 0; } // :241-248
-
+    const int t = i + (p.instance ? 0 : p.ranges[2 * n]);
+    if ((uint32_t)t >= (uint32_t)p.T) return 0;                                                        // :228-233
+    const uint32_t i0 = (uint32_t)p.tri[t * 3 + 0], i1 = (uint32_t)p.tri[t * 3 + 1], i2 = (uint32_t)p.tri[t * 3 + 2];
+    if (i0 >= (uint32_t)p.V || i1 >= (uint32_t)p.V || i2 >= (uint32_t)p.V) return 0;                  // :241-248
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
-    float4 q0 = vb[i0], q1 = vb[i1], q2 = vb[i2];
-    float v[3][4];
+    const float4 q0 = vb[i0], q1 = vb[i1], q2 = vb[i2];
     // Viewport-tile transform (:262-267); identity when the image is one viewport.
     v[0][0] = __fmaf_rn(q0.x, p.vp.xs, q0.w * p.vp.xo); v[0][1] = __fmaf_rn(q0.y, p.vp.ys, q0.w * p.vp.yo); v[0][2] = q0.z; v[0][3] = q0.w;
     v[1][0] = __fmaf_rn(q1.x, p.vp.xs, q1.w * p.vp.xo); v[1][1] = __fmaf_rn(q1.y, p.vp.ys, q1.w * p.vp.yo); v[1][2] = q1.z; v[1][3] = q1.w;
     v[2][0] = __fmaf_rn(q2.x, p.vp.xs, q2.w * p.vp.xo); v[2][1] = __fmaf_rn(q2.y, p.vp.ys, q2.w * p.vp.yo); v[2][2] = q2.z; v[2][3] = q2.w;
+    return t + 1;
+}
+
+constexpr uint32_t kClipBox = 0x0000FFFEu;               // LDS stage only: the slot's triangle waits for the clipper
+
+// Common path of one triangle: its record and AABB go to the block's LDS stage; a triangle that needs the
+// clipper is queued instead (its block processes the queue densely afterwards, see k_setup).
+__device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, int* s_hist, uint4* stage, uint32_t* boxStage, int* clipq, int* clipn)
+{
+#pragma clang fp contract(off)
+    float v[3][4];
+    const int id = fetch_tri(p, n, i, v);
+    if (!id) { *boxStage = kEmptyBox; return; }
 
     // Trivial reject: all vertices beyond one frustum plane (:271-283).
     if ((v[0][3] < fabsf(v[0][0])) || (v[0][3] < fabsf(v[0][1])) || (v[0][3] < fabsf(v[0][2]))) {
@@ -365,7 +384,7 @@ __device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int
             out |= (v[0][3] < +v[0][ax]) & (v[1][3] < +v[1][ax]) & (v[2][3] < +v[2][ax]);
             out |= (v[0][3] < -v[0][ax]) & (v[1][3] < -v[1][ax]) & (v[2][3] < -v[2][ax]);
         }
-        if (out) { empty_box(); return 0; }
+        if (out) { *boxStage = kEmptyBox; return; }
     }
 
     bool inside = true;
@@ -375,32 +394,27 @@ __device__ __forceinline__ int setup_one(const SetupParams& p, int n, int i, int
 
     if (inside) {                                                                    // :329-352
         SubTri st;
-        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, t + 1, s_hist, stage, boxStage);
-        else empty_box();
-    } else if (clipq) {
-        clipq[atomicAdd(clipn, 1)] = i;
+        if (snap_cull_setup(p.vp, v, st)) emit_record(p, n, i, st, id, s_hist, stage, boxStage);
+        else *boxStage = kEmptyBox;
     } else {
-        return setup_clipped(p, n, i, v, t + 1, s_hist, stage, boxStage, pool_slot);
+        clipq[atomicAdd(clipn, 1)] = i;
+        *boxStage = kClipBox;
     }
-    return 0;
 }
 
-
+// Dynamic LDS: int s_hist[3 * binsX * binsY].
 __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int blocksPerImage)
 {
-    // The parameter block is read where it lies, in the kernarg segment.  Handing the by-value struct to the
-    // (deliberately not inlined) clipper by reference made the compiler copy it into scratch in every thread:
-    // 144 B x 655k threads = 94 MB of this kernel's 170 MB of HBM writes (PMC WRITE_SIZE), and every
-    // later field access was a scratch load.
+    // The parameter block is read where it lies, in the kernarg segment (a by-value struct handed on by
+    // reference is copied into scratch by every thread: measured 94 MB of HBM writes in an earlier version).
     (void)p_arg;
     const SetupParams& p = *(const SetupParams*)__builtin_amdgcn_kernarg_segment_ptr();
     // image-major work list cut into one contiguous chunk per XCD (an image's vertices are fetched into one L2)
     int bxi, byi, n;
     if (!decode_block(blocksPerImage, 1, p.N, bxi, byi, n)) return;
-    __shared__ int s_hist[3 * kMaxBins];              // per bin: count, max slot + 1, INT_MAX - min slot
+    extern __shared__ int s_hist[];                   // [3][bins]: count, max slot + 1, INT_MAX - min slot per bin
     const int nb = p.binsX * p.binsY;
-    for (int b = threadIdx.x; b < nb; b += 256) { s_hist[b] = 0; s_hist[kMaxBins + b] = 0; s_hist[2 * kMaxBins + b] = 0; }
-    __syncthreads();
+    for (int b = threadIdx.x; b < 3 * nb; b += 256) s_hist[b] = 0;
     // Records are staged in LDS (one 64-byte record per thread) and written out as contiguous 1 KiB
     // rows: the L2 is write-through, so four 16-byte stores at a 64-byte stride per lane would reach
     // memory as four partial-line writes each (measured: 4x the bytes).  Slots of culled triangles
@@ -411,35 +425,15 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
     // whole waves waiting for their few clipped lanes.  Pass 1 queues those triangles, pass 2 runs
     // the clipper on the queue with consecutive lanes.
     __shared__ int s_clipq[256];
-    __shared__ int s_clipn;
+    __shared__ int s_clipn, s_poolNeed, s_poolBase;
     if (threadIdx.x == 0) s_clipn = 0;
+    __shared__ uint32_t s_box[256];                          // AABBs of the block's slots: written out as one 1 KiB row
     __syncthreads();
     const int i0 = bxi * 256;
-    __shared__ uint32_t s_box[256];                          // AABBs of the block's slots: written out as one 1 KiB row
-    s_box[threadIdx.x] = kEmptyBox;                          // slots of queued (clipped) triangles are filled in pass 2b
     setup_one(p, n, i0 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4, &s_box[threadIdx.x], s_clipq, &s_clipn);
     __syncthreads();
-    // 2a: count the sub-triangles, reserve the block's pool slots with ONE global atomic (a returning
-    // atomic per clipped triangle on the image's counter serialises: measured 0.5 ms on the stress scene)
-    __shared__ int s_poolNeed, s_poolBase;
-    if (s_clipn > 0) {                                       // uniform: blocks without clipped triangles skip all of it
-        if (threadIdx.x == 0) { s_poolNeed = 0; s_poolBase = 0; }
-        __syncthreads();
-        const bool clip = (int)threadIdx.x < s_clipn;
-        const int ci = clip ? s_clipq[threadIdx.x] : 0;
-        int poolOff = 0;
-        if (clip) {
-            const int ns = setup_one(p, n, ci, s_hist, nullptr, nullptr, nullptr, nullptr, -1);
-            if (ns > 1) poolOff = atomicAdd(&s_poolNeed, ns - 1);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_poolNeed > 0) s_poolBase = atomicAdd(&p.poolCount[n], s_poolNeed);
-        __syncthreads();
-        // 2b: emit
-        if (clip) setup_one(p, n, ci, s_hist, s_rec + (ci - i0) * 4, &s_box[ci - i0], nullptr, nullptr, s_poolBase + poolOff);
-        __syncthreads();
-    }
     {
+        // Slots waiting for the clipper are left out (pass 2 writes them in place).
         const int cnt = p.instance ? p.T : p.ranges[2 * n + 1];
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const int slot0 = bxi * 256 + wave * 64;
@@ -448,17 +442,44 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int q = k * 64 + lane;                       // 16-byte chunk inside the wave's 4 KiB
-            if (slot0 + (q >> 2) < cnt) dst[q] = src[q];
+            if (slot0 + (q >> 2) < cnt && s_box[wave * 64 + (q >> 2)] != kClipBox) dst[q] = src[q];
         }
-        if (slot0 + lane < cnt) p.bbox[(size_t)n * p.slots + slot0 + lane] = s_box[threadIdx.x];
+        if (slot0 + lane < cnt && s_box[threadIdx.x] != kClipBox) p.bbox[(size_t)n * p.slots + slot0 + lane] = s_box[threadIdx.x];
     }
+    // Pass 2, rounds of up to kClipLanes queued triangles (uniform: blocks without any skip all of it).  Every
+    // triangle is clipped ONCE, its sub-triangles wait in private memory while the round's pool slots are reserved
+    // with one global atomic (a returning atomic per clipped triangle on the image's counter serialises: measured
+    // 0.5 ms on the stress scene), then they are written in place.
+    if (s_clipn > 0) {
+        __syncthreads();                                     // the record stage has left: it becomes the clipper's workspace
+        float* wsAll = (float*)s_rec;
+        for (int base = 0; base < s_clipn; base += kClipLanes) {
+            if (threadIdx.x == 0) { s_poolNeed = 0; s_poolBase = 0; }
+            __syncthreads();
+            const bool act = (int)threadIdx.x < kClipLanes && base + (int)threadIdx.x < s_clipn;
+            SubTri st[kSubPerTri];
+            int ns = 0, ci = 0, id = 0, poolOff = 0;
+            if (act) {
+                ci = s_clipq[base + threadIdx.x];
+                float v[3][4];
+                id = fetch_tri(p, n, ci, v);
+                ns = clip_prepare(p, v, wsAll + threadIdx.x, st);
+                if (ns > 1) poolOff = atomicAdd(&s_poolNeed, ns - 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0 && s_poolNeed > 0) s_poolBase = atomicAdd(&p.poolCount[n], s_poolNeed);
+            __syncthreads();
+            if (act) clip_emit(p, n, ci, st, ns, id, s_hist, s_poolBase + poolOff);
+        }
+    }
+    __syncthreads();
     // One global atomic per non-empty bin per block (instead of one per triangle).
     for (int b = threadIdx.x; b < nb; b += 256) {
-        int c = s_hist[b];
+        const int c = s_hist[b];
         if (c) {
             const size_t o = (size_t)n * nb + b;
             atomicAdd(&p.binCount[o], c);
-            if (s_hist[kMaxBins + b]) { atomicMax(&p.binHi[o], s_hist[kMaxBins + b]); atomicMax(&p.binLoInv[o], s_hist[2 * kMaxBins + b]); }
+            if (s_hist[nb + b]) { atomicMax(&p.binHi[o], s_hist[nb + b]); atomicMax(&p.binLoInv[o], s_hist[2 * nb + b]); }
         }
     }
 }
@@ -1223,13 +1244,14 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         int* poolPeak = shortPool ? (int*)(sb + L.poolPeak) : nullptr;
         if (shortPool && tx == 0 && ty == 0) NVDR_HIP_CHECK(hipMemsetAsync(poolPeak, 0, 4, stream));
         const int bpi = (max_tri + 255) / 256;
+        const size_t histBytes = (size_t)3 * binsX * binsY * sizeof(int);
         // Every call leaves the control block zeroed (k_order); it is cleared here only when the caller
         // cannot vouch for that (first use of the buffer, another layout, a failed call).
         if (!scratch_clean && tx == 0 && ty == 0)                  // later viewport tiles inherit the clean block from the tile before
             NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, L.ctlEnd - L.pool, stream));
         {
             ProfileScope ps("raster_setup", stream);
-            hipLaunchKernelGGL(k_setup, dim3((unsigned)((((long long)bpi * N + 7) / 8) * 8)), dim3(256), 0, stream, sp, bpi);
+            hipLaunchKernelGGL(k_setup, dim3((unsigned)((((long long)bpi * N + 7) / 8) * 8)), dim3(256), histBytes, stream, sp, bpi);
         }
         NVDR_LAUNCH_CHECK();
         {

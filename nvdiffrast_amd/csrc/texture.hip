@@ -491,14 +491,33 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
     }
 }
 
+// The four texels of a cube footprint, all channels at once (vector loads for C_CT = 2 / 4), with the corner rule of
+// fetch_quad applied per channel (same summation order, so both routes give identical bits).
+template <int C_CT>
+__device__ __forceinline__ void fetch_quad_vec(const float* base, const Quad& q, int C, float a[4][C_CT > 0 ? C_CT : 1])
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) load_texel<C_CT>(a[k], base, q.tc[k], C);
+    if (q.corner) {
+#pragma unroll
+        for (int c = 0; c < C_CT; c++) {
+            const float avg = (((a[0][c] + a[1][c]) + a[2][c]) + a[3][c]) * 0.33333333f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (q.tc[k] < 0) a[k][c] = avg;
+        }
+    }
+}
+
 // Cube-map forward: same pixel mapping, direction vectors instead of (u,v), footprints that may cross
-// a face edge (three faces at a corner).  Generic channel loop.
-template <int FILTER, bool BIAS_ONLY>
+// a face edge (three faces at a corner).  C_CT = 1..4: channel count known at compile time (texels of 2 and 4 channels
+// are single 8 / 16-byte loads, the output one store); C_CT = 0: generic channel loop.
+template <int FILTER, bool BIAS_ONLY, int C_CT>
 __global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
 {
     int px, py, pz; bool inside;
     if (!tex_pixel(p, px, py, pz, inside) || !inside) return;
-    const int C = p.channels;
+    constexpr int CMAX = C_CT > 0 ? C_CT : 1;
+    const int C = C_CT > 0 ? C_CT : p.channels;
     const int tz = (p.texDepth == 1) ? 0 : pz;
     const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
     const float* puv = p.uv + pidx * 3;
@@ -508,7 +527,15 @@ __global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
     if (FILTER == TEX_NEAREST) {
         int x, y;
         const int tc = tex_index_nearest_cube(p, uv3, tz, x, y);
-        for (int c = 0; c < C; c++) pOut[c] = tc >= 0 ? p.tex[0][tc * C + c] : 0.f;
+        if (C_CT > 0) {
+            float t[CMAX];
+            load_texel<C_CT>(t, p.tex[0], tc, C);
+            if (C_CT == 4) *(float4*)pOut = make_float4(t[0], t[1 % CMAX], t[2 % CMAX], t[3 % CMAX]);
+            else if (C_CT == 2) *(float2*)pOut = make_float2(t[0], t[1 % CMAX]);
+            else for (int c = 0; c < C_CT; c++) pOut[c] = t[c];
+        } else {
+            for (int c = 0; c < C; c++) pOut[c] = tc >= 0 ? p.tex[0][tc * C + c] : 0.f;
+        }
         return;
     }
     int level0, level1; float flevel;
@@ -517,6 +544,21 @@ __global__ __launch_bounds__(256) void k_tex_fwd_cube(const TexParams p)
     const bool second = (FILTER == TEX_LML) && flevel > 0.f;
     Quad q1 = q0;
     if (second) q1 = tex_index_linear_cube(p, uv3, tz, level1);
+    if (C_CT > 0) {
+        float a[4][CMAX], r[CMAX];
+        fetch_quad_vec<C_CT>(p.tex[level0], q0, C, a);
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) r[c] = bilerp1(a[0][c], a[1][c], a[2][c], a[3][c], q0.fu, q0.fv);
+        if (second) {
+            fetch_quad_vec<C_CT>(p.tex[level1], q1, C, a);
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) r[c] = lerp1(r[c], bilerp1(a[0][c], a[1][c], a[2][c], a[3][c], q1.fu, q1.fv), flevel);
+        }
+        if (C_CT == 4) *(float4*)pOut = make_float4(r[0], r[1 % CMAX], r[2 % CMAX], r[3 % CMAX]);
+        else if (C_CT == 2) *(float2*)pOut = make_float2(r[0], r[1 % CMAX]);
+        else for (int c = 0; c < CMAX; c++) pOut[c] = r[c];
+        return;
+    }
     for (int c = 0; c < C; c++) {
         float a[4];
         fetch_quad(p.tex[level0], q0, C, c, a);
@@ -1064,6 +1106,15 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
         else             hipLaunchKernelGGL((k_tex_fwd<FILTER, BO, 0>), grid, dim3(256), 0, stream, p);    \
     } while (0)
 
+#define NVDR_TEX_FWD_CUBE_C(FILTER, BO)                                                                       \
+    do {                                                                                                   \
+        if (vec4)        hipLaunchKernelGGL((k_tex_fwd_cube<FILTER, BO, 4>), grid, dim3(256), 0, stream, p); \
+        else if (C == 3) hipLaunchKernelGGL((k_tex_fwd_cube<FILTER, BO, 3>), grid, dim3(256), 0, stream, p); \
+        else if (vec2)   hipLaunchKernelGGL((k_tex_fwd_cube<FILTER, BO, 2>), grid, dim3(256), 0, stream, p); \
+        else if (C == 1) hipLaunchKernelGGL((k_tex_fwd_cube<FILTER, BO, 1>), grid, dim3(256), 0, stream, p); \
+        else             hipLaunchKernelGGL((k_tex_fwd_cube<FILTER, BO, 0>), grid, dim3(256), 0, stream, p); \
+    } while (0)
+
 extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_host, int L,
                                 const float* uv, const float* uv_da, const float* mip_level_bias,
                                 int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
@@ -1083,12 +1134,10 @@ extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_h
     if (boundary_mode == TEX_B_CUBE) {
         ProfileScope ps("tex_fwd_cube", stream);
         switch (filter_mode) {
-        case TEX_NEAREST: hipLaunchKernelGGL((k_tex_fwd_cube<TEX_NEAREST, false>), grid, dim3(256), 0, stream, p); break;
-        case TEX_LINEAR:  hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LINEAR, false>), grid, dim3(256), 0, stream, p); break;
-        case TEX_LMN:     if (bo) hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LMN, true>), grid, dim3(256), 0, stream, p);
-                          else    hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LMN, false>), grid, dim3(256), 0, stream, p); break;
-        default:          if (bo) hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LML, true>), grid, dim3(256), 0, stream, p);
-                          else    hipLaunchKernelGGL((k_tex_fwd_cube<TEX_LML, false>), grid, dim3(256), 0, stream, p); break;
+        case TEX_NEAREST: NVDR_TEX_FWD_CUBE_C(TEX_NEAREST, false); break;
+        case TEX_LINEAR:  NVDR_TEX_FWD_CUBE_C(TEX_LINEAR, false); break;
+        case TEX_LMN:     if (bo) NVDR_TEX_FWD_CUBE_C(TEX_LMN, true); else NVDR_TEX_FWD_CUBE_C(TEX_LMN, false); break;
+        default:          if (bo) NVDR_TEX_FWD_CUBE_C(TEX_LML, true); else NVDR_TEX_FWD_CUBE_C(TEX_LML, false); break;
         }
     } else {
         ProfileScope ps("tex_fwd", stream);

@@ -32,7 +32,7 @@ def test_single_rank_line():
 
 @pytest.mark.parametrize("workload,scaling,total", [("ch", "weak", 8), ("c4", "strong", 256)])
 def test_two_ranks_are_spawned_and_take_part(workload, scaling, total):
-    flags = ["--gpus", "2", "--workload", workload] + (["--batch", "4"] if workload == "ch" else [])
+    flags = ["--gpus", "2", "--chunks", "4", "--workload", workload] + (["--batch", "4"] if workload == "ch" else [])
     j = _run(*flags)
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["backend"] == "gloo"
     assert j["scaling"] == scaling and j["config"]["total_items"] == total
@@ -40,3 +40,24 @@ def test_two_ranks_are_spawned_and_take_part(workload, scaling, total):
     assert j["config"]["gather_images"] is True and j["config"]["chunks"] == 4
     assert j["gathered_rows_chunk0"] == 2 * (total // 2 // 4)          # every rank's chunk arrived
     assert j["value"] > 0 and j["ms_per_step"] > 0
+
+
+def test_two_ranks_report_the_job_without_the_image_gather_too():
+    j = _run("--gpus", "2", "--batch", "4")
+    c = j["collective"]
+    img = 4 * 32 * 32 * 4 * 4                                         # items x res^2 x A x f32 of one rank (dry runs render 32x32)
+    assert c["image_bytes_sent_per_rank_per_step"] == img and c["xgmi_links_per_gpu_used"] == 1
+    assert c["value_without_image_gather"] > 0 and c["ms_per_step_without_image_gather"] > 0
+
+
+def test_collectives_can_be_forced_on_a_single_rank():
+    """`--force-collectives`: the N > 1 code path with a process group of one (what tests/test_gpu_bench.py runs over RCCL)."""
+    j = _run("--force-collectives", "--batch", "4", "--chunks", "2")
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1 and j["backend"] == "gloo"
+    assert j["config"]["gather_images"] is True and j["config"]["chunks"] == 2 and j["collective"] is not None
+
+
+def test_default_chunking_keeps_chunks_large():
+    """Chunks below ~64 items leave the GPU waiting for the host (measured on the MI355X): the default never makes them."""
+    assert _run("--gpus", "2", "--batch", "4")["config"]["chunks"] == 1
+    assert _run("--gpus", "2", "--workload", "c4")["config"]["chunks"] == 2          # 128 items per rank

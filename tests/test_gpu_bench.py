@@ -1,0 +1,44 @@
+"""bench.py on the GPU: the default line's contract, and the N > 1 code path (RCCL process group, broadcast of the shared
+geometry, chunked image all-gather overlapped with rendering, shared-gradient all-reduce) run with a group of one --
+the only way to execute those RCCL calls on a 1-GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", *flags],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_default_line_contract():
+    j = _bench("--batch", "8", "--cpu-items", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 2 and j["dtype"] == "f32"
+    assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
+    assert j["parity"]["tri_id_mismatches"] == 0
+    assert j["parity"]["g_pos_max_abs_err"] <= 1e-5 * max(1.0, j["parity"]["g_pos_max_abs"])
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.parametrize("workload", ["ch", "c4"])
+def test_collective_path_over_rccl_with_one_rank(workload):
+    j = _bench("--force-collectives", "--workload", workload, "--batch", "8", "--chunks", "4", "--no-cpu-baseline")
+    assert j["rccl_ranks"] == 1 and j["config"]["gather_images"] is True and j["config"]["chunks"] == 4
+    assert j["value"] > 0 and j["collective"]["value_without_image_gather"] > 0

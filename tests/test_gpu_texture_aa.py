@@ -143,7 +143,7 @@ def _cube_dirs(rng, N, H, W):
 
 
 @pytest.mark.parametrize("fm", FILTERS)
-@pytest.mark.parametrize("C,tex_n", [(3, 1), (4, 2), (1, 1)])
+@pytest.mark.parametrize("C,tex_n", [(3, 1), (4, 2), (1, 1), (2, 2), (5, 1)])    # every k_tex_fwd_cube<.., C_CT> variant
 def test_cube_forward_backward(dr, oracle, fm, C, tex_n):
     rng = np.random.default_rng(200 + C)
     N, H, W = 2, 23, 19
