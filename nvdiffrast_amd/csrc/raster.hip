@@ -568,7 +568,7 @@ struct FineShared {
 //  2. fragments: each lane pops the set bits of its mask, evaluates the U32 depth plane
 //     and merges depth<<32|~id into the tile's key array with an LDS 64-bit atomic min.
 // Bit b of the mask is pixel (x, y) = (7 - (b & 7), 7 - (b >> 3)) of the tile.
-template <bool PEEL>
+template <bool PEEL, bool DBG = false>
 __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
                                              int wave, int lane, int n, int head, int npairs, int btx0, int bty0)
 {
@@ -590,6 +590,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     uint32_t e1 = q1.y + (uint32_t)__mul24(A1, X0) + (uint32_t)__mul24(B1, Y0);
     uint32_t e2 = q2.x + (uint32_t)__mul24(A2, X0) + (uint32_t)__mul24(B2, Y0);
 
+    if (DBG && (p.dbg & 256)) { if (q0.x == 0x12345u && q3.w == 77u) sh.key[0][0][lane] = q1.x; return; }      // experiment: no coverage, no fragments
     uint32_t mhi = 0, mlo = 0;                   // rows 0..3 -> mhi, rows 4..7 -> mlo (sign bits = outside)
 #pragma unroll
     for (int y = 0; y < 8; y++) {
@@ -604,29 +605,67 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     }
     uint64_t m = act ? ~(((uint64_t)mhi << 32) | mlo) : 0ull;
     if (__ballot(m != 0) == 0) return;
+    if (DBG && (p.dbg & 128)) { if (m == 0x123456789ull) sh.key[0][0][lane] = m; return; }                       // experiment: no fragment loop
 
     const uint32_t zx = q2.y, zy = q2.z;
-    const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
     const uint32_t d0 = q2.w + zx * (uint32_t)X0 + zy * (uint32_t)Y0;   // depth at the tile origin
     const uint32_t idk = ~q3.x;
-    unsigned long long* keys = sh.key[tyl][tx];
-    // Start each lane at a different bit so that equal masks do not all hit one LDS address.
-    const int rot = lane & 63;
-    m = (m >> rot) | (m << ((64 - rot) & 63));
-    while (__ballot(m != 0)) {
-        if (m != 0) {
-            int b = (__builtin_ctzll(m) + rot) & 63;
-            m &= m - 1;
-            uint32_t x = 7u - (uint32_t)(b & 7), y = 7u - (uint32_t)(b >> 3);
-            // zx*x + zy*y with x,y < 8 via 24-bit multiplies (FineRaster.inl:348 depth, U32 wrap).
-            uint32_t depth = d0 + __umul24(zxl, x) + (__umul24(zxh, x) << 24) + __umul24(zyl, y) + (__umul24(zyh, y) << 24);
-            bool live = true;
-            if (PEEL) {
-                uint32_t pz = p.peel[((size_t)n * p.Hp + (Y0 + (int)y + p.vp.offy)) * p.Wp + (X0 + (int)x + p.vp.offx)];
-                live = depth > pz;                                               // FineRaster.inl:349
+    const int tile = tyl * kBinTiles + tx;
+
+    // Fragments.  Triangles are small: a wave's 64 masks hold 4 fragments on average but 28 at the maximum
+    // (measured on the headline batch), so letting every lane pop its own bits keeps 63 lanes waiting for the
+    // fullest one.  Masks above kCoop fragments are therefore rasterised by the WHOLE wave, one lane per pixel
+    // (the mask is the execution mask: no bit scanning, one conflict-free LDS atomic per mask); the others are
+    // popped by their own lanes, at most kCoop rounds.
+    constexpr int kCoop = 8;
+    const bool big = __popcll(m) > kCoop;
+    uint64_t heavy = __ballot(big);
+    const uint32_t m0lo = (uint32_t)m, m0hi = (uint32_t)(m >> 32);
+    if (big) m = 0;
+    if (__ballot(m != 0)) {
+        const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
+        unsigned long long* keys = sh.key[tyl][tx];
+        // Start each lane at a different bit so that equal masks do not all hit one LDS address.
+        const int rot = lane & 63;
+        m = (m >> rot) | (m << ((64 - rot) & 63));
+        while (__ballot(m != 0)) {
+            if (m != 0) {
+                int b = (__builtin_ctzll(m) + rot) & 63;
+                m &= m - 1;
+                uint32_t x = 7u - (uint32_t)(b & 7), y = 7u - (uint32_t)(b >> 3);
+                // zx*x + zy*y with x,y < 8 via 24-bit multiplies (FineRaster.inl:348 depth, U32 wrap).
+                uint32_t depth = d0 + __umul24(zxl, x) + (__umul24(zxh, x) << 24) + __umul24(zyl, y) + (__umul24(zyh, y) << 24);
+                bool live = true;
+                if (PEEL) {
+                    uint32_t pz = p.peel[((size_t)n * p.Hp + (Y0 + (int)y + p.vp.offy)) * p.Wp + (X0 + (int)x + p.vp.offx)];
+                    live = depth > pz;                                               // FineRaster.inl:349
+                }
+                if (live) atomicMin(&keys[y * 8 + x], ((unsigned long long)depth << 32) | idk);
             }
-            if (live) atomicMin(&keys[y * 8 + x], ((unsigned long long)depth << 32) | idk);
         }
+    }
+    if (heavy) {
+        const uint32_t xl = 7u - (uint32_t)(lane & 7), yl = 7u - (uint32_t)(lane >> 3);       // this lane's pixel: bit `lane` of a mask
+        unsigned long long* keys0 = &sh.key[0][0][0];
+        do {
+            const int src = __builtin_ctzll(heavy);
+            heavy &= heavy - 1;
+            const uint64_t sm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m0hi, src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)m0lo, src);
+            const uint32_t szx = (uint32_t)__builtin_amdgcn_readlane((int)zx, src), szy = (uint32_t)__builtin_amdgcn_readlane((int)zy, src);
+            const uint32_t sd0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, src), sidk = (uint32_t)__builtin_amdgcn_readlane((int)idk, src);
+            const int stile = __builtin_amdgcn_readlane(tile, src);
+            if ((sm >> lane) & 1ull) {
+                const uint32_t depth = sd0 + __umul24(szx & 0xFFFFFFu, xl) + (__umul24(szx >> 24, xl) << 24)
+                                           + __umul24(szy & 0xFFFFFFu, yl) + (__umul24(szy >> 24, yl) << 24);
+                bool live = true;
+                if (PEEL) {
+                    const int sX0 = __builtin_amdgcn_readlane(X0, src), sY0 = __builtin_amdgcn_readlane(Y0, src);
+                    const uint32_t pz = p.peel[((size_t)n * p.Hp + (sY0 + (int)yl + p.vp.offy)) * p.Wp + (sX0 + (int)xl + p.vp.offx)];
+                    live = depth > pz;
+                }
+                if (live) atomicMin(&keys0[stile * 64 + (int)(yl * 8 + xl)], ((unsigned long long)depth << 32) | sidk);
+            }
+        } while (heavy);
     }
 }
 
@@ -817,7 +856,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     if (DBG) dbgSurv += __popcll(m);
                     if (qn >= 64) {
                         __builtin_amdgcn_wave_barrier();
-                        raster_pairs<PEEL>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0);
+                        raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0);
                         __builtin_amdgcn_wave_barrier();
                         head = (head + 64) & (kQueueSize - 1);
                         qn -= 64;
@@ -825,7 +864,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 }
                 if (qn > 0) {
                     __builtin_amdgcn_wave_barrier();
-                    raster_pairs<PEEL>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0);
+                    raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -1279,7 +1318,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         if (dbgMode) hipLaunchKernelGGL((k_fine<PEEL, WD, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);   \
         else         hipLaunchKernelGGL((k_fine<PEEL, WD, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);   \
     } while (0)
-            const bool dbgMode = fp.dbgbuf != nullptr || (fp.dbg & (4 | 8 | 16)) != 0;
+            const bool dbgMode = fp.dbgbuf != nullptr || (fp.dbg & (4 | 8 | 16 | 128 | 256 | 512)) != 0;
             if (peel_depth && depth_out)       NVDR_FINE(true, true);
             else if (peel_depth)               NVDR_FINE(true, false);
             else if (depth_out)                NVDR_FINE(false, true);

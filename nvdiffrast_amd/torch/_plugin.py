@@ -91,8 +91,38 @@ def _require(cond, func, msg):
         _fail(func, msg)
 
 
+# Host time matters: with small batches the step time IS the host's (BASELINE config 2 at batch 16 is host-bound on an
+# MI355X).  The public torch.cuda helpers (current_stream(), the `device` context manager) cost ~6 us per use in index
+# normalisation and object construction; these go to the same C entry points directly.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    """The current hipStream_t of `device` as an integer."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` that does nothing in the usual case of `dev` being the current device already."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _pad8(x):
@@ -116,6 +146,7 @@ class RasterizeCRStateWrapper:
         self.retired = []        # scratch buffers that recorded graphs still point to
         self.reported_bytes = 0
         self.pools = {}          # (N, max_tri) -> clip-pool slots per image that the last call in growing mode needed
+        self.sizes = {}          # (N, max_tri, H, W, pool) -> scratch bytes
         self.depth = None        # current depth surface  [N,Hp,Wp] int32 (u32 bits)
         self.peel = None         # previous layer's depth surface
 
@@ -148,6 +179,16 @@ class RasterizeCRStateWrapper:
 
     def mark_clean(self, layout):
         self.clean_layout = layout
+
+    def scratch_bytes(self, lib, n, max_tri, h, w, pool):
+        """nvdr_rasterize_scratch_bytes[_pool], remembered per shape (a pure function of its arguments)."""
+        key = (n, max_tri, h, w, pool)
+        v = self.sizes.get(key)
+        if v is None:
+            if len(self.sizes) > 256:
+                self.sizes.clear()
+            v = self.sizes[key] = int(lib.nvdr_rasterize_scratch_bytes_pool(n, max_tri, h, w, pool))
+        return v
 
     def pool_hint(self, n, max_tri):
         """Clip-pool slots per image to start with in growing mode: what this shape needed last time, else the worst
@@ -201,7 +242,7 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
         ranges_dev = ranges.to(dev)
 
     lib = _capi.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         out = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         out_db = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         # Depth surfaces exist only while peeling (peeling_idx >= 0); layer k > 0 reads layer k-1's.
@@ -211,7 +252,7 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
 
         # Scratch policy (include/nvdr_hip.h, NVDR_OPT_SCRATCH_LIMIT_MB): the worst case while it is affordable -- no
         # overflow possible, no host synchronisation, hipGraph-capturable -- otherwise a clip pool that grows on demand.
-        worst = lib.nvdr_rasterize_scratch_bytes(depth, max_tri, height, width)
+        worst = state.scratch_bytes(lib, depth, max_tri, height, width, -1)
         adaptive = worst > (int(lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB)) << 20)
         pool = state.pool_hint(depth, max_tri) if adaptive else -1
         if adaptive and _is_capturing(dev):
@@ -219,7 +260,7 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
                       "growing clip pool used instead reads a counter back after each call and cannot be captured into a "
                       "graph (raise the limit to capture)" % (worst >> 20))
         while True:
-            nbytes = lib.nvdr_rasterize_scratch_bytes_pool(depth, max_tri, height, width, pool)
+            nbytes = state.scratch_bytes(lib, depth, max_tri, height, width, pool)
             layout = (depth, max_tri, height, width, pool)
             scratch, clean = state.get_scratch(nbytes, dev, layout)
             rc = lib.nvdr_rasterize_fwd(pos.data_ptr(), tri.data_ptr(), _capi.ptr(ranges_dev),
@@ -272,7 +313,7 @@ def rasterize_grad_db(pos, tri, out, dy, ddb):
     dy_ = dy.contiguous()
     ddb_ = ddb.contiguous() if enable_db else None
     V = pos.size(1) if instance_mode else pos.size(0)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         grad = torch.zeros_like(pos)
         rc = _capi.load().nvdr_rasterize_grad(pos.data_ptr(), tri.data_ptr(), out.data_ptr(), dy_.data_ptr(),
                                               _capi.ptr(ddb_), int(instance_mode), depth, V, tri.size(0),
@@ -335,7 +376,7 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec)
     N, H, W = rast.size(0), rast.size(1), rast.size(2)
     D = (A if diff_attrs_all else len(diff_attrs_vec)) if enable_da else 0
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         out = torch.empty((N, H, W, A), dtype=torch.float32, device=dev)
         out_da = torch.empty((N, H, W, 2 * D), dtype=torch.float32, device=dev)
         rc = _capi.load().nvdr_interpolate_fwd(attr.data_ptr(), rast.data_ptr(), tri.data_ptr(),
@@ -398,7 +439,7 @@ def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_
     dy_ = dy.contiguous()
     dda_ = dda.contiguous() if enable_da else None
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         g_attr = torch.zeros_like(attr)
         g_rast = torch.empty_like(rast)
         g_rast_db = torch.empty_like(rast_db) if enable_da else None
@@ -473,7 +514,7 @@ def texture_construct_mip(tex, max_mip_level, cube_mode):
     _check_f32(fn, tex=tex)
     _check_tex_shape(fn, tex, cube_mode)
     L, lw, lh, off, total = _mip_info(tex.shape, cube_mode, max_mip_level, fn)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         mip = torch.empty((total,), dtype=torch.float32, device=dev)
         tn, th, tw, tc = _tex_dims(tex, cube_mode)
         rc = _capi.load().nvdr_texture_construct_mip(tex.data_ptr(), tn, th, tw, tc,
@@ -588,7 +629,7 @@ def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filt
     tn, th, tw, C = _tex_dims(tex, boundary_mode == _BOUNDARY_CUBE)
     n, H, W = uv.size(0), uv.size(1), uv.size(2)
     ptrs, L = _capi.ptr_array(levels)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         out = torch.empty((n, H, W, C), dtype=torch.float32, device=dev)
         rc = _capi.load().nvdr_texture_fwd(tex.data_ptr(), ptrs, L, uv.data_ptr(),
                                            uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
@@ -619,7 +660,7 @@ def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wr
     has_stack = len(mip_stack) > 0
     ptrs, L = _capi.ptr_array(levels)
     gptrs, _ = _capi.ptr_array(g_levels)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         g_tex = torch.zeros_like(tex)
         g_uv = g_uv_da = g_bias = None
         if filter_mode != _FILTER_NEAREST:
@@ -675,7 +716,7 @@ def antialias_construct_topology_hash(tri):
     _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
     lib = _capi.load()
     nbytes = lib.nvdr_antialias_hash_bytes(tri.size(0))
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         ev_hash = torch.empty((nbytes // 4,), dtype=torch.int32, device=dev)        # cleared by the library
         rc = lib.nvdr_antialias_construct_topology_hash(tri.data_ptr(), tri.size(0), ev_hash.data_ptr(), nbytes, _stream(dev))
     _capi.check(rc, fn)
@@ -721,7 +762,7 @@ def antialias_fwd(color, rast, pos, tri, topology_hash_wrap):
     N, H, W, C = color.shape
     V = pos.size(1 if instance_mode else 0)
     lib = _capi.load()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         out = torch.empty_like(color)                                                   # the library copies color into it
         work_buffer = torch.empty((N * W * H * 8 + 4,), dtype=torch.float32, device=dev)
         rc = lib.nvdr_antialias_fwd(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(),
@@ -743,7 +784,7 @@ def antialias_grad(color, rast, pos, tri, dy, work_buffer):
     N, H, W, C = color.shape
     V = pos.size(1 if instance_mode else 0)
     dy_ = dy.contiguous()
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         g_color = torch.empty_like(dy_)                                                  # the library copies dy into it
         g_pos = torch.zeros_like(pos)
         rc = _capi.load().nvdr_antialias_grad(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(),

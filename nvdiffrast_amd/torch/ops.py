@@ -49,10 +49,16 @@ def _tensors(**named):
         assert isinstance(value, torch.Tensor), f"{name} must be a torch.Tensor"
 
 
+_NO_RANGES = None
+
+
 def _as_ranges(ranges):
     """Range-mode table, or the empty CPU [0,2] int32 tensor the plugin expects in instanced mode (ops.py:125-126)."""
     if ranges is None:
-        return torch.empty(size=(0, 2), dtype=torch.int32, device="cpu")
+        global _NO_RANGES
+        if _NO_RANGES is None:
+            _NO_RANGES = torch.empty(size=(0, 2), dtype=torch.int32, device="cpu")
+        return _NO_RANGES
     _tensors(ranges=ranges)
     return ranges
 

@@ -6,7 +6,7 @@ import nvdiffrast_amd.torch as dr
 from nvdiffrast_amd import _capi
 from nvdiffrast_amd.utils import m10k_batch
 
-N = 64
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 lib = _capi.load()
 lib.nvdr_debug_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda", 0)
