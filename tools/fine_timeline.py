@@ -44,3 +44,18 @@ ts = np.linspace(0, end.max(), 20)
 print("alive WGs over time:", [(int(((start <= t) & (end > t)).sum())) for t in ts])
 emp = cnt == 0
 print("empty WGs: %d, their duration mean %.1f" % (emp.sum(), dur[emp].mean()))
+# per-XCD chunks of the work order (item index = position in the order; 8 contiguous chunks)
+per = (nwg + 7) // 8
+for x in range(8):
+    sl = slice(x * per, min((x + 1) * per, nwg))
+    print("XCD chunk %d: last end %.1f us, sum of WG durations %.0f us, non-empty %d, triangles listed %d"
+          % (x, end[sl].max(), dur[sl].sum(), int((cnt[sl] > 0).sum()), int(cnt[sl].sum())))
+# occupancy seen by each starting workgroup inside its XCD chunk (128 slots per XCD = 32 CUs x 4)
+for x in range(8):
+    sl = slice(x * per, min((x + 1) * per, nwg))
+    s_, e_ = start[sl], end[sl]
+    order_ = np.argsort(s_)
+    alive_at_start = np.array([int(((s_ <= s_[i]) & (e_ > s_[i])).sum()) for i in order_])
+    qs = [int(alive_at_start[int(f * (len(order_) - 1))]) for f in (0.1, 0.25, 0.5, 0.75, 0.9, 1.0)]
+    ts = np.linspace(0, e_.max(), 9)[1:-1]
+    print("XCD %d: alive when a WG starts (10/25/50/75/90/100%% of starts): %s; alive over time %s" % (x, qs, [int(((s_ <= t) & (e_ > t)).sum()) for t in ts]))
