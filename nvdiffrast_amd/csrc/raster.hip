@@ -620,18 +620,16 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     constexpr int kCoop = 8;
     const bool big = __popcll(m) > kCoop;
     uint64_t heavy = __ballot(big);
-    const uint32_t m0lo = (uint32_t)m, m0hi = (uint32_t)(m >> 32);
-    if (big) m = 0;
-    if (__ballot(m != 0)) {
+    if (__ballot(!big && m != 0)) {
         const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
         unsigned long long* keys = sh.key[tyl][tx];
         // Start each lane at a different bit so that equal masks do not all hit one LDS address.
         const int rot = lane & 63;
-        m = (m >> rot) | (m << ((64 - rot) & 63));
-        while (__ballot(m != 0)) {
-            if (m != 0) {
-                int b = (__builtin_ctzll(m) + rot) & 63;
-                m &= m - 1;
+        uint64_t ml = big ? 0ull : (m >> rot) | (m << ((64 - rot) & 63));
+        while (__ballot(ml != 0)) {
+            if (ml != 0) {
+                int b = (__builtin_ctzll(ml) + rot) & 63;
+                ml &= ml - 1;
                 uint32_t x = 7u - (uint32_t)(b & 7), y = 7u - (uint32_t)(b >> 3);
                 // zx*x + zy*y with x,y < 8 via 24-bit multiplies (FineRaster.inl:348 depth, U32 wrap).
                 uint32_t depth = d0 + __umul24(zxl, x) + (__umul24(zxh, x) << 24) + __umul24(zyl, y) + (__umul24(zyh, y) << 24);
@@ -644,6 +642,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
             }
         }
     }
+    const uint32_t m0lo = (uint32_t)m, m0hi = (uint32_t)(m >> 32);
     if (heavy) {
         const uint32_t xl = 7u - (uint32_t)(lane & 7), yl = 7u - (uint32_t)(lane >> 3);       // this lane's pixel: bit `lane` of a mask
         unsigned long long* keys0 = &sh.key[0][0][0];
@@ -654,7 +653,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
             const uint32_t szx = (uint32_t)__builtin_amdgcn_readlane((int)zx, src), szy = (uint32_t)__builtin_amdgcn_readlane((int)zy, src);
             const uint32_t sd0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, src), sidk = (uint32_t)__builtin_amdgcn_readlane((int)idk, src);
             const int stile = __builtin_amdgcn_readlane(tile, src);
-            if ((sm >> lane) & 1ull) {
+            if (__builtin_amdgcn_inverse_ballot_w64(sm)) {                 // the mask IS the execution mask
                 const uint32_t depth = sd0 + __umul24(szx & 0xFFFFFFu, xl) + (__umul24(szx >> 24, xl) << 24)
                                            + __umul24(szy & 0xFFFFFFu, yl) + (__umul24(szy >> 24, yl) << 24);
                 bool live = true;
@@ -694,7 +693,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lx = lane & 7, ly = lane >> 3;
     const int vpwPad = (p.vp.vpw + 7) & ~7, vphPad = (p.vp.vph + 7) & ~7;
 
     unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
@@ -746,9 +744,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             return b;
         };
 
-        uint4 cur = done ? make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox) : load_boxes(scan);
-
         for (;;) {
+            // (re)loaded at the start of every pass instead of being carried over the raster stage: four registers
+            // less there, where the kernel sits at its 64-VGPR budget
+            uint4 cur = done ? make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox) : load_boxes(scan);
             // ---- filter: compact this bin's triangles into the LDS list ----------------
             while (!done) {
                 if (found + sh.count >= binTris) { done = true; break; }       // every triangle of the bin is listed
@@ -878,6 +877,11 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 
     if (DBG && p.dbgbuf) tstamp[5] = wall_clock64();
     // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w -----------
+    // The lane number is taken afresh here (opaque to the compiler): derived from the copy made at kernel entry, the
+    // shader's per-lane constants were computed up front and parked in scratch across the raster stage.
+    int laneS;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(laneS));
+    const int lx = laneS & 7, ly = laneS >> 3;
     const int tileRow = wave / kWavesPerRow, tile0 = (wave % kWavesPerRow) * kTilesPerWave;
     const int ty = bty0 + tileRow;
     const int Y = ty * 8 + ly;                  // viewport-local pixel row
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     for (int tt = 0; tt < kTilesPerWave; tt++) {
         const int t = tile0 + tt;
         const int X = (btx0 + t) * 8 + lx;
-        const unsigned long long key = sh.key[tileRow][t][lane];
+        const unsigned long long key = sh.key[tileRow][t][laneS];
         if (WRITE_DEPTH) {
             if (X < vpwPad && Y < vphPad)
                 p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
