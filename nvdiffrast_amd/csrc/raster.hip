@@ -789,7 +789,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             const int cnt = min(sh.count, kListCap);
             found += cnt;
             // The bin is finished when every wave has scanned to the end or all its triangles are listed.
-            const int allDone = __syncthreads_and((done || found >= binTris) ? 1 : 0);
+            const int allDone = __builtin_amdgcn_readfirstlane(__syncthreads_and((done || found >= binTris) ? 1 : 0));   // uniform: keep it in an SGPR
             unsigned long long tf1 = (DBG && p.dbgbuf) ? wall_clock64() : 0;
             if (DBG) { tstamp[1] += 1; tstamp[4] += cnt; }
 
@@ -807,8 +807,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 if (nx == 0) ny = 0;
             };
             if (wave == 0) {
-                // exclusive scan of the pair counts: lane l owns entries [l*8, l*8+8)
+                // exclusive scan of the pair counts: lane l owns entries [l*7, l*7+7)
                 constexpr int kPer = (kListCap + 63) / 64;
+                int lane;                                   // taken afresh: keeps lane * kPer out of the long-lived registers
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
                 int local[kPer], sum = 0;
 #pragma unroll
                 for (int i = 0; i < kPer; i++) {
