@@ -183,7 +183,9 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="nccl", device_id=dev)     # RCCL over xGMI
 
+    from nvdiffrast_amd import parallel
     from nvdiffrast_amd.parallel import broadcast_shared, allreduce_shared_grads, gather_items_async, shard_range
+    parallel.force_collectives(args.force_collectives)
     from nvdiffrast_amd.utils import m10k_batch
 
     wl = WORKLOADS[args.workload]

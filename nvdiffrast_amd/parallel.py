@@ -17,8 +17,24 @@ import torch
 import torch.distributed as dist
 
 
+_FORCE = False
+
+
+def force_collectives(enable=True):
+    """Testing aid: issue the collectives even in a process group of one (lets a 1-GPU box execute the RCCL calls)."""
+    global _FORCE
+    _FORCE = bool(enable)
+
+
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _single():
+    """True when there is nobody to talk to (and the collectives are not forced for testing)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and not _FORCE
 
 
 def rank():
@@ -42,7 +58,7 @@ def shard_items(t, dim=0):
 
 def broadcast_shared(tensors, src=0):
     """In-place broadcast of shared (non per-item) tensors from ``src``."""
-    if world() == 1:
+    if _single():
         return tensors
     for t in tensors:
         dist.broadcast(t, src=src)
@@ -51,7 +67,7 @@ def broadcast_shared(tensors, src=0):
 
 def allreduce_shared_grads(params):
     """Sum the gradients of shared inputs over ranks (one flat bucket, one collective)."""
-    if world() == 1:
+    if _single():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:
@@ -74,7 +90,7 @@ def gather_items(local, n_items=None):
     ``n_items`` = size of the whole batch when it was split with ``shard_range``; when it is not given the
     ranks first exchange their local counts, so that every rank sizes the collective identically whatever the split."""
     w = world()
-    if w == 1:
+    if _single():
         return local
     if n_items is not None:
         counts = [shard_range(n_items, w, r)[1] for r in range(w)]
@@ -101,7 +117,7 @@ def gather_items_async(local, out=None):
     on the current stream), so kernels launched afterwards overlap it; ``work.wait()`` makes the current stream
     wait for the result.  ``out`` = receive buffer of a previous call to reuse.  World size 1: (no-op work, local)."""
     w = world()
-    if w == 1:
+    if _single():
         return _Done(), local
     shape = (w * local.shape[0],) + tuple(local.shape[1:])
     if out is None or tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device:
