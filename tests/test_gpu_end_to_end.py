@@ -124,5 +124,5 @@ def test_pipeline_matches_committed_fixture(dr):
     for k, v in got.items():
         ref = fx["out_" + k]
         err = np.abs(v.detach().cpu().numpy() - ref).max()
-        tol = 1e-5 * max(1.0, float(np.abs(ref).max())) * (4.0 if k.startswith("g_") else 1.0)   # f32 sums of O(100) terms
+        tol = 1e-5 * max(1.0, float(np.abs(ref).max()))          # measured: <= 0.26 of this for the colours, <= 0.1 for the gradients
         assert err <= tol, (k, err, tol)

@@ -73,9 +73,10 @@ def test_clipping_and_huge_triangles(dr, oracle):
     r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, tri, (128, 200))
     mism = int((r[..., 3] != ro[..., 3]).sum())
     assert mism == 0
-    # barycentrics of clipped triangles can be ill-conditioned near w=0; compare where well-posed
+    # vertices with w <= 0 can make a pixel's barycentrics non-finite in the reference's formula; where they are finite
+    # the 1e-5 bar holds (measured: 4e-7 against the oracle, 5e-7 against the reference itself)
     ok = np.isfinite(ro).all(-1) & np.isfinite(r).all(-1)
-    assert np.abs(r[ok][:, :3] - ro[ok][:, :3]).max() <= 1e-4
+    assert np.abs(r[ok][:, :3] - ro[ok][:, :3]).max() <= ATOL
 
 
 def test_depth_ties_and_duplicates(dr, oracle):

@@ -58,16 +58,16 @@ def test_texture_forward_backward(dr, oracle, fm, bm, C, tex_n):
 
     oo = oracle.texture(tex, uv, uv_da, bias, **kw)
     g = oracle.texture_grad(tex, uv, dy, uv_da, bias, **kw)
-    frac = 2e-3 if mip else 0.0
+    frac = 0.0          # no pixel is exempted (an earlier version allowed 0.2 % at mip-level boundaries; none differ)
     _close(out.detach().cpu().numpy(), oo, ATOL, frac)
     _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), frac)
     if fm == "nearest":
         assert t_uv.grad is None or float(t_uv.grad.abs().max()) == 0.0
     else:
-        _close(t_uv.grad.cpu().numpy(), g["uv"], _tol(g["uv"]) * 4, frac)
+        _close(t_uv.grad.cpu().numpy(), g["uv"], _tol(g["uv"]), frac)
     if fm == "linear-mipmap-linear":
-        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]) * 4, frac)
-        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]) * 4, frac)
+        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]), frac)
+        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]), frac)
     elif mip:
         assert t_da.grad is None and t_bias.grad is None
 
@@ -81,10 +81,10 @@ def test_bias_only_and_uvda_only(dr, oracle):
     for da, b in ((uv_da, None), (None, bias)):
         for fm in ("linear-mipmap-nearest", "linear-mipmap-linear"):
             o = dr.texture(_t(tex), _t(uv), None if da is None else _t(da), None if b is None else _t(b), filter_mode=fm)
-            _close(o.cpu().numpy(), oracle.texture(tex, uv, da, b, filter_mode=fm), ATOL, 2e-3)
+            _close(o.cpu().numpy(), oracle.texture(tex, uv, da, b, filter_mode=fm), ATOL)
     # max_mip_level limits the chain; 0 degrades to plain bilinear (ops.py:411-412)
     o = dr.texture(_t(tex), _t(uv), _t(uv_da), filter_mode="linear-mipmap-linear", max_mip_level=2)
-    _close(o.cpu().numpy(), oracle.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear", max_mip_level=2), ATOL, 2e-3)
+    _close(o.cpu().numpy(), oracle.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear", max_mip_level=2), ATOL)
     o = dr.texture(_t(tex), _t(uv), _t(uv_da), filter_mode="linear-mipmap-linear", max_mip_level=0)
     _close(o.cpu().numpy(), oracle.texture(tex, uv, filter_mode="linear"), ATOL)
 
@@ -125,10 +125,10 @@ def test_custom_mip_stack_gradients(dr, oracle):
     out = dr.texture(t_tex, _t(uv), None, _t(bias), mip=t_lv, filter_mode="linear-mipmap-linear")
     out.backward(_t(dy))
     g = oracle.texture_grad(tex, uv, dy, None, bias, mip=levels, filter_mode="linear-mipmap-linear")
-    _close(out.detach().cpu().numpy(), oracle.texture(tex, uv, None, bias, mip=levels, filter_mode="linear-mipmap-linear"), ATOL, 2e-3)
-    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), 2e-3)
+    _close(out.detach().cpu().numpy(), oracle.texture(tex, uv, None, bias, mip=levels, filter_mode="linear-mipmap-linear"), ATOL)
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]))
     for k in range(3):
-        _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]), 2e-3)
+        _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]))
 
 
 # ------------------------------------------------------------------------------ cube maps
@@ -163,14 +163,14 @@ def test_cube_forward_backward(dr, oracle, fm, C, tex_n):
     out.backward(_t(dy))
     oo = oracle.texture(tex, v, da, bias, **kw)
     g = oracle.texture_grad(tex, v, dy, da, bias, **kw)
-    frac = 3e-3 if mip else 0.0
+    frac = 0.0
     _close(out.detach().cpu().numpy(), oo, ATOL, frac)
     _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), frac)
     if fm != "nearest":
-        _close(t_v.grad.cpu().numpy(), g["uv"], _tol(g["uv"]) * 4, frac)
+        _close(t_v.grad.cpu().numpy(), g["uv"], _tol(g["uv"]), frac)
     if fm == "linear-mipmap-linear":
-        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]) * 4, frac)
-        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]) * 4, frac)
+        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]), frac)
+        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]), frac)
 
 
 def test_cube_mips(dr, oracle):
@@ -192,7 +192,7 @@ def test_cube_mips(dr, oracle):
     o.backward(_t(dy))
     g = oracle.texture_grad(tex, v, dy, da, mip=levels, boundary_mode="cube")
     for k in range(2):
-        _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]), 3e-3)
+        _close(t_lv[k].grad.cpu().numpy(), g["mip"][k], _tol(g["mip"][k]))
 
 
 # ------------------------------------------------------------------------------ antialias
@@ -218,7 +218,7 @@ def test_antialias_forward_backward(dr, oracle):
     assert (oo != color).any(-1).sum() > 200                      # the scene has silhouettes
     _close(out.detach().cpu().numpy(), oo, ATOL)
     _close(t_col.grad.cpu().numpy(), gc, _tol(gc))
-    _close(t_pos.grad.cpu().numpy(), gp, _tol(gp) * 4)
+    _close(t_pos.grad.cpu().numpy(), gp, _tol(gp))
     # prebuilt topology hash and gradient boost
     h = dr.antialias_construct_topology_hash(tri)
     t_pos2 = _t(b["pos"]).requires_grad_(True)
@@ -246,7 +246,7 @@ def test_antialias_range_mode_and_split_vertices(dr, oracle):
     out.backward(_t(dy))
     _close(out.detach().cpu().numpy(), oracle.antialias(color, ro, pos, tri), ATOL)
     gc, gp = oracle.antialias_grad(color, ro, pos, tri, dy)
-    _close(t_pos.grad.cpu().numpy(), gp, _tol(gp) * 4)
+    _close(t_pos.grad.cpu().numpy(), gp, _tol(gp))
 
 
 def test_full_chain_config3(dr, oracle):
@@ -274,16 +274,16 @@ def test_full_chain_config3(dr, oracle):
     outo = oracle.antialias(colo, ro, b["pos"], b["tri"])
     assert (rast[..., 3].detach().cpu().numpy() != ro[..., 3]).sum() == 0
     _close(uv_da.detach().cpu().numpy(), uvdao, _tol(uvdao))
-    _close(col.detach().cpu().numpy(), colo, 2e-5, 2e-3)
-    _close(out.detach().cpu().numpy(), outo, 2e-5, 2e-3)
+    _close(col.detach().cpu().numpy(), colo, 2e-5)
+    _close(out.detach().cpu().numpy(), outo, 2e-5)
 
     g_col, g_pos_aa = oracle.antialias_grad(colo, ro, b["pos"], b["tri"], G)
     tg = oracle.texture_grad(tex, uvo, g_col, uvdao, filter_mode="linear-mipmap-linear")
     g_uvattr, g_rast, g_rdb = oracle.interpolate_grad(b["uv"], ro, b["tri"], tg["uv"], rast_db=rdbo, dda=tg["uv_da"], diff_attrs="all")
     g_pos = oracle.rasterize_grad(b["pos"], b["tri"], ro, g_rast, ddb=g_rdb) + g_pos_aa
-    _close(t_tex.grad.cpu().numpy(), tg["tex"], _tol(tg["tex"]) * 4, 2e-3)
-    _close(uvattr.grad.cpu().numpy(), g_uvattr, _tol(g_uvattr) * 8, 5e-3)
-    _close(pos.grad.cpu().numpy(), g_pos, _tol(g_pos) * 8, 5e-3)
+    _close(t_tex.grad.cpu().numpy(), tg["tex"], _tol(tg["tex"]))
+    _close(uvattr.grad.cpu().numpy(), g_uvattr, _tol(g_uvattr) * 8)
+    _close(pos.grad.cpu().numpy(), g_pos, _tol(g_pos) * 8)
 
 
 @pytest.mark.parametrize("bm", ["wrap", "clamp", "zero"])
@@ -312,8 +312,8 @@ def test_texture_backward_on_constant_uv_regions(dr, oracle, fm, bm):
     out = dr.texture(t_tex, t_uv, t_da, t_bias, **kw)
     out.backward(_t(dy))
     g = oracle.texture_grad(tex, uv, dy, uv_da if mip else None, bias, **kw)
-    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]), 2e-3)
-    _close(t_uv.grad.cpu().numpy(), g["uv"], _tol(g["uv"]) * 4, 2e-3)
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]))
+    _close(t_uv.grad.cpu().numpy(), g["uv"], _tol(g["uv"]))
     if fm == "linear-mipmap-linear":
-        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]) * 4, 2e-3)
-        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]) * 4, 2e-3)
+        _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]))
+        _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]))
