@@ -570,7 +570,8 @@ struct FineShared {
 // Bit b of the mask is pixel (x, y) = (7 - (b & 7), 7 - (b >> 3)) of the tile.
 template <bool PEEL, bool DBG = false>
 __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
-                                             int wave, int lane, int n, int head, int npairs, int btx0, int bty0)
+                                             int wave, int lane, int n, int head, int npairs, int btx0, int bty0,
+                                             unsigned long long* dbgNonEmpty = nullptr)
 {
     const bool act = lane < npairs;
     const uint32_t q = sh.queue[wave][(head + lane) & (kQueueSize - 1)];
@@ -604,6 +605,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
         e0 += (uint32_t)B0; e1 += (uint32_t)B1; e2 += (uint32_t)B2;
     }
     uint64_t m = act ? ~(((uint64_t)mhi << 32) | mlo) : 0ull;
+    if (DBG && dbgNonEmpty) *dbgNonEmpty += __popcll(__ballot(m != 0));
     if (__ballot(m != 0) == 0) return;
     if (DBG && (p.dbg & 128)) { if (m == 0x123456789ull) sh.key[0][0][lane] = m; return; }                       // experiment: no fragment loop
 
@@ -704,7 +706,8 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
     __syncthreads();
 
-    if (binTris > 0) {
+    // DBG experiment: bins at or above a triangle threshold (NVDR_DEBUG bits 20..31, x16) skip their raster stage
+    if (binTris > 0 && !(DBG && (p.dbg >> 20) && binTris >= ((p.dbg >> 20) & 0xFFF) * 16)) {
         const int direct = p.instance ? p.T : p.ranges[2 * n + 1];
         const int pool   = min(p.poolFinal[n], p.slots - p.poolBase);
         // Index space scanned by the filter: [0, dlen) = the bin's range of direct slots (k_setup
@@ -854,10 +857,9 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     if (keep) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
                         (uint16_t)((uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12));
                     qn += __popcll(m);
-                    if (DBG) dbgSurv += __popcll(m);
                     if (qn >= 64) {
                         __builtin_amdgcn_wave_barrier();
-                        raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0);
+                        raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0, DBG ? &dbgSurv : nullptr);
                         __builtin_amdgcn_wave_barrier();
                         head = (head + 64) & (kQueueSize - 1);
                         qn -= 64;
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 }
                 if (qn > 0) {
                     __builtin_amdgcn_wave_barrier();
-                    raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0);
+                    raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0, DBG ? &dbgSurv : nullptr);
                     __builtin_amdgcn_wave_barrier();
                 }
             }

@@ -4,7 +4,7 @@ sys.path.insert(0, '/root/repo')
 import nvdiffrast_amd.torch as dr
 from nvdiffrast_amd import _capi
 from nvdiffrast_amd.utils import m10k_batch
-N = 64
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 64      # run with NVDR_DEBUG=64
 lib = _capi.load()
 lib.nvdr_debug_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda", 0)
@@ -20,7 +20,7 @@ dr.rasterize(ctx, pos, tri, (512, 512)); torch.cuda.synchronize()
 lib.nvdr_debug_buffer(None)
 d = buf.cpu().numpy().reshape(nwg, W, 8).astype(np.float64)
 cand = d[:, 0, 2]; surv = d[:, :, 3].sum(1); cnt = d[:, 0, 4]
-print("total tris in lists %.0f, candidate pairs %.0f, surviving pairs %.0f" % (cnt.sum(), cand.sum(), surv.sum()))
+print("total tris in lists %.0f, (triangle, tile) pairs %.0f, pairs with a non-empty coverage mask %.0f" % (cnt.sum(), cand.sum(), surv.sum()))
 i = np.argsort(-cand)[:6]
 for k in i: print("WG", k, "cnt", cnt[k], "cand", cand[k], "surv", surv[k])
-print("pairs per tri mean %.2f; survivors per tri %.2f" % (cand.sum() / cnt.sum(), surv.sum() / cnt.sum()))
+print("pairs per tri mean %.2f; non-empty per tri %.2f" % (cand.sum() / cnt.sum(), surv.sum() / cnt.sum()))
