@@ -50,6 +50,11 @@ constexpr int kBinTiles   = 8;                           // bin = 8x8 tiles = 64
 // (at most (2048 / 64)^2 = 1024 bins per viewport tile: scratch_layout sizes the per-bin arrays from the actual count)
 constexpr int kFineWaves  = 8;                           // one wave per row of eight 8x8 tiles
 constexpr int kFineThreads = kFineWaves * 64;
+constexpr int kSplitTris  = 768;                         // bins with at least this many triangles are shared by several workgroups
+constexpr int kSplitPart  = 384;                         // ... of about this many triangles each
+constexpr int kSplitMaxParts = 4;
+constexpr int kSplitsPerChunk = 16;                      // at most this many shared bins per XCD chunk of the work order
+constexpr int kHelpersPerChunk = kSplitsPerChunk * (kSplitMaxParts - 1);
 constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in the pair ring)
 constexpr int kWavesPerRow = kFineWaves / kBinTiles;        // waves sharing one row of eight 8x8 tiles
 constexpr int kTilesPerWave = kBinTiles / kWavesPerRow;
@@ -494,9 +499,14 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
 // block is left as the next rasterize call needs it (no memset launch in front of every call).
 __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int* __restrict__ binHi, int* __restrict__ binLoInv,
                                                 int* __restrict__ poolCount, int* __restrict__ poolFinal, int* __restrict__ poolPeak, int N,
-                                                int4* __restrict__ order, int totalBins)
+                                                int4* __restrict__ order, int totalBins,
+                                                int* __restrict__ splitInfo, int4* __restrict__ helpers, int* __restrict__ splitDone,
+                                                int splitTris, int splitPart)
 {
     __shared__ int s_bucket[32];
+    __shared__ int s_nsplit, s_nhelp;
+    if (threadIdx.x == 0) { s_nsplit = 0; s_nhelp = 0; }
+    for (int h = threadIdx.x; h < kHelpersPerChunk; h += 1024) helpers[blockIdx.x * kHelpersPerChunk + h] = make_int4(-1, 0, 0, 0);
     const int perXcd = (totalBins + 7) >> 3;
     const int lo = blockIdx.x * perXcd, hi = min(lo + perXcd, totalBins);
     if (threadIdx.x < 32) s_bucket[threadIdx.x] = 0;
@@ -520,6 +530,22 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         const int scanLo = hiSlot ? ((0x7FFFFFFF - binLoInv[i]) & ~3) : 0;
         const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
         order[lo + pos] = make_int4(i, c, scanLo, dlen);
+        // Bins with very many triangles (edge-on meshes) would each keep one workgroup busy for as long as the whole
+        // launch takes: their slot range is shared by up to kSplitMaxParts workgroups (k_fine merges the parts' keys).
+        int info = 0;
+        if (c >= splitTris) {
+            const int parts = max(2, min(kSplitMaxParts, (c + splitPart - 1) / splitPart));
+            const int sidx = atomicAdd(&s_nsplit, 1);
+            if (sidx < kSplitsPerChunk) {
+                const int hbase = atomicAdd(&s_nhelp, parts - 1);
+                const int gs = blockIdx.x * kSplitsPerChunk + sidx;                 // split number of this call
+                for (int k = 1; k < parts; k++)
+                    helpers[blockIdx.x * kHelpersPerChunk + hbase + k - 1] = make_int4(i, (gs << 8) | (k << 4) | parts, scanLo, dlen);
+                info = (gs << 8) | parts;
+                splitDone[gs] = 0;
+            }
+        }
+        splitInfo[lo + pos] = info;
         binCount[i] = 0; binHi[i] = 0; binLoInv[i] = 0;   // this thread was the bin's only reader in this pass
     }
     if (blockIdx.x == 0)
@@ -537,6 +563,8 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
 struct FineParams {
     const uint4* rec; const uint32_t* bbox; const int* poolFinal; const int* ranges;
     const int4* order;
+    const int* splitInfo; const int4* helpers;          // bins shared by several workgroups (k_order)
+    unsigned long long* splitKeys; int* splitDone;      // their merged key arrays [split][64 tiles][64 px] and arrival counters
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
@@ -672,7 +700,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
 
 // DBG = development instrumentation (per-workgroup phase timestamps and experiment switches); the
 // production instantiation carries none of it (the kernel sits at the 64-VGPR limit of 4 workgroups/CU).
-template <bool PEEL, bool WRITE_DEPTH, bool DBG>
+template <bool PEEL, bool WRITE_DEPTH, bool DBG, bool SPLIT>
 __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fine(const FineParams p)
 {
     __shared__ FineShared sh;
@@ -681,17 +709,33 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     // and walk that XCD's chunk of the heavy-first order produced by k_order, so an image's
     // records / AABBs / vertices stay in one L2 and long bins start early.  Placement and
     // order only affect speed.
+    // SPLIT (the launch has too few bins to fill the chip, so its length is the lifetime of the bin with the most
+    // triangles): the first kHelpersPerChunk block numbers of every XCD are helper slots -- extra workgroups for the
+    // heaviest bins, each taking a part of the bin's slot range (they start together with those bins).
     const int perXcd = (p.totalBins + 7) >> 3;
-    const int item = (int)(blockIdx.x & 7) * perXcd + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= perXcd || item >= p.totalBins) return;
-    const int4 it4 = p.order[item];
+    const int xcd = (int)(blockIdx.x & 7), jj = (int)(blockIdx.x >> 3) - (SPLIT ? kHelpersPerChunk : 0);
+    int4 it4;
+    int item = -1, part = 0, parts = 1, split = 0;
+    if (SPLIT && jj < 0) {
+        it4 = p.helpers[xcd * kHelpersPerChunk + jj + kHelpersPerChunk];
+        if (it4.x < 0) return;
+        split = it4.y >> 8; part = (it4.y >> 4) & 15; parts = it4.y & 15;
+    } else {
+        item = xcd * perXcd + jj;
+        if (jj >= perXcd || item >= p.totalBins) return;
+        it4 = p.order[item];
+        if (SPLIT) {
+            const int info = p.splitInfo[item];
+            if (info) { split = info >> 8; parts = info & 15; }
+        }
+    }
     const int work = it4.x;
     const int binsPerImage = p.binsX * p.binsY;
     const int n   = work / binsPerImage;
     const int bin = work - n * binsPerImage;
     const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
     const int btx0 = binX * kBinTiles, bty0 = binY * kBinTiles;
-    const int binTris = it4.y;                  // triangles whose AABB touches this bin
+    const int binTris = (SPLIT && parts > 1) ? 0x7FFFFFFF : it4.y;   // triangles whose AABB touches this bin (a part does not know its share: it scans its whole range)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -715,12 +759,17 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         // in index order, so this is a small part of the image's triangles), [dlen, dlen + pool) =
         // the clipper's pool slots.  Four consecutive slots per lane per step.
         const int scanLo = it4.z, dlen = it4.w;
-        const int total = dlen + pool;
+        int total = dlen + pool, scanBeg = 0;
+        if (SPLIT && parts > 1) {                   // this workgroup's part of the index space (multiples of 4 slots)
+            const int per = ((total + parts - 1) / parts + 3) & ~3;
+            scanBeg = min(part * per, total);
+            total = min(scanBeg + per, total);
+        }
         const uint32_t* gbox = p.bbox + (size_t)n * p.slots;
         const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
 
         constexpr int kStep = kFineThreads * 4;     // slots per workgroup step
-        int scan = wave * 256;                      // this wave's position in the scanned index space
+        int scan = scanBeg + wave * 256;            // this wave's position in the scanned index space
         int sub = 0, skip = 0;                      // resume point inside the current group of 4x64 slots
         bool done = (scan >= total);
         int found = 0;                              // list entries consumed by earlier rounds
@@ -880,13 +929,32 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     }
 
     if (DBG && p.dbgbuf) tstamp[5] = wall_clock64();
-    // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w -----------
     // The lane number is taken afresh here (opaque to the compiler): derived from the copy made at kernel entry, the
     // shader's per-lane constants were computed up front and parked in scratch across the raster stage.
     int laneS;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(laneS));
     const int lx = laneS & 7, ly = laneS >> 3;
     const int tileRow = wave / kWavesPerRow, tile0 = (wave % kWavesPerRow) * kTilesPerWave;
+    // ---- a bin shared by several workgroups: every part publishes its key array in memory and counts itself in; the
+    //      part that arrives last takes the minimum over all parts (the same order-free rule as in LDS) and shades the
+    //      bin, the others are done.  Only RETURNING device-scope atomics touch the shared memory: they execute at the
+    //      memory side, coherently for the whole device -- no dependence on where the parts run and no cache
+    //      write-back (an agent-scope fence in a kernel with hundreds of MB of stores in flight costs more than the
+    //      split saves: 126 -> 220 us) -- and a part knows its keys are in place when the old values have come back,
+    //      which is before it counts itself in.  Nothing needs initialising: every part writes all of its keys.
+    unsigned long long* gkeys = p.splitKeys + (size_t)split * (kSplitMaxParts * 4096) + (size_t)(tileRow * kBinTiles + tile0) * 64 + laneS;
+    if (SPLIT && parts > 1) {
+        unsigned long long seen = 0ull;
+#pragma unroll
+        for (int tt = 0; tt < kTilesPerWave; tt++)
+            seen |= atomicExch(&gkeys[part * 4096 + tt * 64], sh.key[tileRow][tile0 + tt][laneS]);
+        const int landed = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(seen == 1ull)));      // consumes every returned value (whatever it is)
+        __syncthreads();
+        if (threadIdx.x == 0) sh.count = (atomicAdd(&p.splitDone[split], 1 + (landed >> 8)) == parts - 1) ? 1 : 0;
+        __syncthreads();
+        if (!sh.count) return;
+    }
+    // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w -----------
     const int ty = bty0 + tileRow;
     const int Y = ty * 8 + ly;                  // viewport-local pixel row
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
@@ -894,7 +962,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     for (int tt = 0; tt < kTilesPerWave; tt++) {
         const int t = tile0 + tt;
         const int X = (btx0 + t) * 8 + lx;
-        const unsigned long long key = sh.key[tileRow][t][laneS];
+        unsigned long long key = sh.key[tileRow][t][laneS];
+        if (SPLIT)
+            for (int q = 0; q < parts; q++)                                      // (parts > 1: the last part only)
+                if (parts > 1 && q != part) key = min(key, atomicMin(&gkeys[q * 4096 + tt * 64], ~0ull));     // a read at the coherent point
         if (WRITE_DEPTH) {
             if (X < vpwPad && Y < vphPad)
                 p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
@@ -950,7 +1021,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             store_streaming((float4*)p.out_db + pidx, odb);
         }
     }
-    if (DBG && p.dbgbuf && lane == 0) {
+    if (DBG && p.dbgbuf && lane == 0 && item >= 0) {
         unsigned long long* d = p.dbgbuf + ((size_t)item * kFineWaves + wave) * 8;
         d[0] = tstamp[0]; d[1] = tstamp[1]; d[2] = tstamp[2]; d[3] = tstamp[3]; d[4] = tstamp[4]; d[5] = tstamp[5]; d[6] = wall_clock64(); d[7] = (unsigned long long)work;
     }
@@ -1176,7 +1247,7 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 // Host side
 // ---------------------------------------------------------------------------------
 
-struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, poolPeak, order, total; int slots, poolBase, maxBins, poolSlots; };
+struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, poolPeak, order, splitInfo, helpers, splitDone, splitKeys, total; int slots, poolBase, maxBins, poolSlots; };
 
 // pool_per_image: slots per image for the clipper's extra sub-triangles; < 0 or >= 6 * max_tri = the worst case.
 static ScratchLayout scratch_layout(int N, int max_tri, int H, int W, long long pool_per_image = -1)
@@ -1204,13 +1275,34 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W, long long 
     L.poolFinal = align_up(L.ctlEnd, 256);
     L.poolPeak = align_up(L.poolFinal + (size_t)N * 4, 256);
     L.order = align_up(L.poolPeak + 4, 256);
-    L.total = align_up(L.order + (size_t)N * L.maxBins * 16, 256);
+    // bins shared by several workgroups (k_order / k_fine): per work item a split descriptor, per XCD chunk the helper
+    // items, per split an arrival counter and one key array per part (64 tiles x 64 pixels x 8 B)
+    L.splitInfo = align_up(L.order + (size_t)N * L.maxBins * 16, 256);
+    L.helpers = align_up(L.splitInfo + (size_t)N * L.maxBins * 4, 256);
+    L.splitDone = align_up(L.helpers + (size_t)8 * kHelpersPerChunk * 16, 256);
+    L.splitKeys = align_up(L.splitDone + (size_t)8 * kSplitsPerChunk * 4, 256);
+    L.total = align_up(L.splitKeys + (size_t)8 * kSplitsPerChunk * kSplitMaxParts * 4096 * 8, 256);
     return L;
 }
 
 }  // namespace nvdr
 
 using namespace nvdr;
+
+// Workgroups of k_fine the device keeps resident: 4 per CU (40 KB of LDS, 8 waves each).
+static int resident_fine_workgroups()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!cached[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus * 4;
+    }
+    return cached[dev];
+}
 
 extern "C" size_t nvdr_rasterize_scratch_bytes(int N, int max_tri, int H, int W)
 {
@@ -1301,9 +1393,17 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
             hipLaunchKernelGGL(k_setup, dim3((unsigned)((((long long)bpi * N + 7) / 8) * 8)), dim3(256), histBytes, stream, sp, bpi);
         }
         NVDR_LAUNCH_CHECK();
+        // Bins with very many triangles are shared by several workgroups only when the launch cannot hide them: with
+        // fewer bins than two rounds of resident workgroups the launch is as long as its heaviest bin (batch 16 at
+        // 512^2: k_fine 91 -> 57 us); with more, the helpers' extra list building costs more than the shorter tail
+        // gains (batch 64: 126 -> 130 us).
+        const bool dbgMode = debug_buffer() != nullptr || (debug_flags() & (4 | 8 | 16 | 128 | 256 | 512)) != 0;
+        const bool split = !dbgMode && totalBins <= 2 * resident_fine_workgroups() && !(debug_flags() & 1048576);
+        const int splitTris = split ? kSplitTris : 0x7FFFFFFF, splitPart = kSplitPart;
         {
             ProfileScope ps("raster_order", stream);
-            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, poolPeak, N, order, totalBins);
+            hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, poolPeak, N, order, totalBins,
+                               (int*)(sb + L.splitInfo), (int4*)(sb + L.helpers), (int*)(sb + L.splitDone), splitTris, splitPart);
         }
         NVDR_LAUNCH_CHECK();
 
@@ -1313,20 +1413,22 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.W = W; fp.H = H; fp.Wp = Wp; fp.Hp = Hp; fp.vp = vp;
         fp.binsX = binsX; fp.binsY = binsY; fp.totalBins = totalBins;
         fp.order = order;
+        fp.splitInfo = (const int*)(sb + L.splitInfo); fp.helpers = (const int4*)(sb + L.helpers);
+        fp.splitKeys = (unsigned long long*)(sb + L.splitKeys); fp.splitDone = (int*)(sb + L.splitDone);
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
         fp.dbg = debug_flags();
         fp.dbgbuf = debug_buffer();
-        const int grid = ((totalBins + 7) / 8) * 8;
+        const int grid = ((totalBins + 7) / 8) * 8 + (split ? 8 * kHelpersPerChunk : 0);          // + the helper slots of every XCD
         {
             ProfileScope ps("raster_fine", stream);
-#define NVDR_FINE(PEEL, WD)                                                                                           \
-    do {                                                                                                              \
-        if (dbgMode) hipLaunchKernelGGL((k_fine<PEEL, WD, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);   \
-        else         hipLaunchKernelGGL((k_fine<PEEL, WD, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);   \
+#define NVDR_FINE(PEEL, WD)                                                                                                    \
+    do {                                                                                                                       \
+        if (dbgMode)    hipLaunchKernelGGL((k_fine<PEEL, WD, true, false>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
+        else if (split) hipLaunchKernelGGL((k_fine<PEEL, WD, false, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
+        else            hipLaunchKernelGGL((k_fine<PEEL, WD, false, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
     } while (0)
-            const bool dbgMode = fp.dbgbuf != nullptr || (fp.dbg & (4 | 8 | 16 | 128 | 256 | 512)) != 0;
             if (peel_depth && depth_out)       NVDR_FINE(true, true);
             else if (peel_depth)               NVDR_FINE(true, false);
             else if (depth_out)                NVDR_FINE(false, true);

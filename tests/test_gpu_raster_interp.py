@@ -196,3 +196,30 @@ def test_viewport_tiling_beyond_2048(dr, oracle):
     b = m10k_batch(1, seed=30, nx=12, ny=8)
     r, rdb, ro, rdbo = _raster_pair(dr, oracle, b["pos"], b["tri"], (2100, 2500))
     _check_raster(r, rdb, ro, rdbo)
+
+
+def test_bins_shared_by_several_workgroups(dr, oracle):
+    """A mesh squeezed into a narrow strip puts thousands of triangles into single 64x64-px bins; in a small launch such
+    bins are shared by up to four workgroups (k_order helper items; k_fine merges the parts' keys through memory and the
+    last part shades).  Ids and U32 depths must not notice -- also through depth peeling (the PEEL / depth-surface
+    instantiations of the shared path)."""
+    b = m10k_batch(2, seed=4)
+    pos = b["pos"].copy()
+    pos[..., 0] *= 0.04                                     # 10,000 triangles in a strip ~20 px wide: >2000 per bin
+    res = (512, 512)
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, b["tri"], res)
+    ids = ro[..., 3]
+    counts = np.bincount(ids[ids > 0].astype(np.int64)).size
+    assert counts > 1000                                    # the strip really shows many different triangles
+    _check_raster(r, rdb, ro, rdbo)
+
+    layers = oracle.rasterize_layers(pos, b["tri"], res, 3)
+    ctx = dr.RasterizeCudaContext()
+    with dr.DepthPeeler(ctx, _t(pos), _t(b["tri"]), res) as peeler:
+        for k in range(3):
+            rk, _ = peeler.rasterize_next_layer()
+            want, _, depth = layers[k]
+            assert (rk[..., 3].cpu().numpy() != want[..., 3]).sum() == 0, "layer %d" % k
+            got_depth = ctx.cpp_wrapper.depth.cpu().numpy().view(np.uint32)[:, :res[0], :res[1]]
+            cov = want[..., 3] > 0
+            assert (got_depth[cov] != np.asarray(depth).view(np.uint32)[:, :res[0], :res[1]][cov]).sum() == 0, "layer %d depth" % k
