@@ -351,6 +351,7 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
                                     float* out, float* out_da, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
     const bool enable_da = rast_db && (diff_all || num_diff > 0);
     InterpParams p;
     int rc = fill_params(p, attr, rast, tri, rast_db, attr_instance, attr_n, N, V, A, T, H, W,
@@ -380,6 +381,7 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
                                      float* g_attr, float* g_rast, float* g_rast_db, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
     const bool enable_da = rast_db && dda && (diff_all || num_diff > 0);
     InterpParams p;
     int rc = fill_params(p, attr, rast, tri, rast_db, attr_instance, attr_n, N, V, A, T, H, W,

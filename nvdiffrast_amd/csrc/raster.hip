@@ -1329,6 +1329,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
                                   float* out, float* out_db, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
     NVDR_REQUIRE(pos && tri && out && out_db && scratch, "rasterize_fwd: null pointer");
     NVDR_REQUIRE(instance_mode || ranges, "rasterize_fwd: range mode needs ranges");
     NVDR_REQUIRE(N > 0 && V > 0 && T > 0 && max_tri > 0, "rasterize_fwd: empty input");
@@ -1445,6 +1446,7 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
                                    float* grad_pos, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
     NVDR_REQUIRE(pos && tri && out && dy && grad_pos, "rasterize_grad: null pointer");
     NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "resolution must be [>0, >0, >0]");
     NVDR_REQUIRE(V > 0 && T > 0, "rasterize_grad: empty input");
