@@ -53,7 +53,7 @@ constexpr int kFineThreads = kFineWaves * 64;
 constexpr int kSplitTris  = 768;                         // bins with at least this many triangles are shared by several workgroups
 constexpr int kSplitPart  = 384;                         // ... of about this many triangles each
 constexpr int kSplitMaxParts = 4;
-constexpr int kSplitsPerChunk = 16;                      // at most this many shared bins per XCD chunk of the work order
+constexpr int kSplitsPerChunk = 32;                      // at most this many shared bins per XCD chunk of the work order
 constexpr int kHelpersPerChunk = kSplitsPerChunk * (kSplitMaxParts - 1);
 constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in the pair ring)
 constexpr int kWavesPerRow = kFineWaves / kBinTiles;        // waves sharing one row of eight 8x8 tiles
@@ -504,8 +504,8 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
                                                 int splitTris, int splitPart)
 {
     __shared__ int s_bucket[32];
-    __shared__ int s_nsplit, s_nhelp;
-    if (threadIdx.x == 0) { s_nsplit = 0; s_nhelp = 0; }
+    __shared__ int4 s_split[kSplitsPerChunk];
+    if (threadIdx.x < kSplitsPerChunk) s_split[threadIdx.x] = make_int4(0, 0, 0, 0);
     for (int h = threadIdx.x; h < kHelpersPerChunk; h += 1024) helpers[blockIdx.x * kHelpersPerChunk + h] = make_int4(-1, 0, 0, 0);
     const int perXcd = (totalBins + 7) >> 3;
     const int lo = blockIdx.x * perXcd, hi = min(lo + perXcd, totalBins);
@@ -532,21 +532,26 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         order[lo + pos] = make_int4(i, c, scanLo, dlen);
         // Bins with very many triangles (edge-on meshes) would each keep one workgroup busy for as long as the whole
         // launch takes: their slot range is shared by up to kSplitMaxParts workgroups (k_fine merges the parts' keys).
+        // The kSplitsPerChunk heaviest bins of the chunk qualify: their position in the heavy-first order is their split number.
         int info = 0;
-        if (c >= splitTris) {
+        if (c >= splitTris && pos < kSplitsPerChunk) {
             const int parts = max(2, min(kSplitMaxParts, (c + splitPart - 1) / splitPart));
-            const int sidx = atomicAdd(&s_nsplit, 1);
-            if (sidx < kSplitsPerChunk) {
-                const int hbase = atomicAdd(&s_nhelp, parts - 1);
-                const int gs = blockIdx.x * kSplitsPerChunk + sidx;                 // split number of this call
-                for (int k = 1; k < parts; k++)
-                    helpers[blockIdx.x * kHelpersPerChunk + hbase + k - 1] = make_int4(i, (gs << 8) | (k << 4) | parts, scanLo, dlen);
-                info = (gs << 8) | parts;
-                splitDone[gs] = 0;
-            }
+            const int gs = blockIdx.x * kSplitsPerChunk + pos;                          // split number of this call
+            info = (gs << 8) | parts;
+            s_split[pos] = make_int4(i, info, scanLo, dlen);
+            splitDone[gs] = 0;
         }
         splitInfo[lo + pos] = info;
         binCount[i] = 0; binHi[i] = 0; binLoInv[i] = 0;   // this thread was the bin's only reader in this pass
+    }
+    // Helper items of the shared bins, packed at the front of the chunk's helper slots (heaviest bin first).
+    __syncthreads();
+    if (threadIdx.x < kSplitsPerChunk && s_split[threadIdx.x].y) {
+        int base = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) if (s_split[q].y) base += (s_split[q].y & 15) - 1;
+        const int4 e = s_split[threadIdx.x];
+        for (int k = 1; k < (e.y & 15); k++)
+            helpers[blockIdx.x * kHelpersPerChunk + base + k - 1] = make_int4(e.x, (e.y & ~0xFF) | (k << 4) | (e.y & 15), e.z, e.w);
     }
     if (blockIdx.x == 0)
         for (int n = threadIdx.x; n < N; n += 1024) {
