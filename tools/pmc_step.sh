@@ -8,11 +8,12 @@ mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 CMD=${PMC_CMD:-"python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline"}
 pass() { leg=$1; shift; timeout 240 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$leg -o $leg --output-format csv -- $CMD > $OUT/$leg.log 2>&1; }
 pass a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY
+pass c SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ATOMIC_RETURN SQ_INSTS_LDS SQ_WAVE_CYCLES
 pass b SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 python - "$@" <<PY
 import csv, glob, collections, sys
 want = sys.argv[1:]
-for leg in "ab":
+for leg in "abc":
     f = glob.glob("$OUT/%s/**/*counter_collection.csv" % leg, recursive=True)
     if not f: print("no csv for", leg); continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
