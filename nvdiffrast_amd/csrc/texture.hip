@@ -931,26 +931,60 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
 
 struct MipParams { const float* in; float* out; int wi, hi, wo, ho, depth, C; };
 
+// One output element (texel x channel) of a mip level: the 2x2 box average of the level above, 1x2 / 2x1 once an
+// extent has reached 1 (texture_kernel.cu:644-704).
+// I = index type: 64-bit for the large levels, 32-bit where the level above is known to be small (64-bit divisions
+// are ~100 instructions each).
+template <typename I>
+__device__ __forceinline__ float mip_element(const MipParams& p, I i)
+{
+    const int c = (int)(i % (I)p.C);
+    I t = i / (I)p.C;
+    const int x = (int)(t % (I)p.wo); t /= (I)p.wo;
+    const int y = (int)(t % (I)p.ho);
+    const int z = (int)(t / (I)p.ho);
+    const float* in = p.in;
+    if (p.wi == 1 || p.hi == 1) {                          // one extent already 1: average the two remaining texels
+        const I i0 = (p.hi == 1) ? ((I)z * p.hi * p.wi + (I)2 * x) : ((I)z * p.hi * p.wi + (I)2 * y * p.wi);
+        const I i1 = (p.hi == 1) ? i0 + 1 : i0 + p.wi;
+        return .5f * (in[i0 * p.C + c] + in[i1 * p.C + c]);
+    }
+    const I i0 = ((I)z * p.hi + (I)2 * y) * p.wi + (I)2 * x;
+    const float v0 = in[i0 * p.C + c], v1 = in[(i0 + 1) * p.C + c];
+    const float v2 = in[(i0 + p.wi) * p.C + c], v3 = in[(i0 + p.wi + 1) * p.C + c];
+    return .25f * (((v0 + v1) + v2) + v3);
+}
+
 __global__ __launch_bounds__(256) void k_mip_build(const MipParams p)
 {
     const long long total = (long long)p.wo * p.ho * p.depth * p.C;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % p.C);
-    long long t = i / p.C;
-    const int x = (int)(t % p.wo); t /= p.wo;
-    const int y = (int)(t % p.ho);
-    const int z = (int)(t / p.ho);
-    const float* in = p.in;
-    if (p.wi == 1 || p.hi == 1) {                          // one extent already 1: average the two remaining texels
-        const long long i0 = (p.hi == 1) ? ((long long)z * p.hi * p.wi + 2ll * x) : ((long long)z * p.hi * p.wi + 2ll * y * p.wi);
-        const long long i1 = (p.hi == 1) ? i0 + 1 : i0 + p.wi;
-        p.out[i] = .5f * (in[i0 * p.C + c] + in[i1 * p.C + c]);
-    } else {
-        const long long i0 = ((long long)z * p.hi + 2ll * y) * p.wi + 2ll * x;
-        const float v0 = in[i0 * p.C + c], v1 = in[(i0 + 1) * p.C + c];
-        const float v2 = in[(i0 + p.wi) * p.C + c], v3 = in[(i0 + p.wi + 1) * p.C + c];
-        p.out[i] = .25f * (((v0 + v1) + v2) + v3);
+    p.out[i] = mip_element<long long>(p, i);
+}
+
+// The small levels at the end of the chain (a few thousand elements and fewer, each depending on the one before) in
+// ONE launch of one workgroup: a launch per level is 6-8 us of latency for microseconds of work.
+struct MipTailParams { const float* in; float* mip; long long off[kTexMaxLevels]; int w[kTexMaxLevels], h[kTexMaxLevels]; int first, last, depth, C; };
+
+constexpr int kMipTailElems = 12288;                       // largest level of the tail (elements = texels x channels x slices)
+
+__global__ __launch_bounds__(1024) void k_mip_build_tail(const MipTailParams q)
+{
+    // Every level is written to memory AND kept in LDS for the next one (a level is a quarter of the one before, so
+    // two buffers alternate): no memory round trip between the levels.
+    __shared__ float s_a[kMipTailElems];
+    __shared__ float s_b[kMipTailElems / 4];
+    for (int l = q.first; l <= q.last; l++) {
+        float* keep = ((l - q.first) & 1) ? s_b : s_a;
+        const float* prev = ((l - q.first) & 1) ? s_a : s_b;
+        MipParams p;
+        p.in = (l == q.first) ? q.in : prev;
+        p.out = q.mip + q.off[l];
+        p.wi = q.w[l - 1]; p.hi = q.h[l - 1]; p.wo = q.w[l]; p.ho = q.h[l]; p.depth = q.depth; p.C = q.C;
+        const int total = p.wo * p.ho * p.depth * p.C;
+        for (int i = threadIdx.x; i < total; i += 1024) { const float v = mip_element<int>(p, i); p.out[i] = v; keep[i] = v; }      // the level above has <= 4 * kMipTailElems elements
+        __syncthreads();
     }
 }
 
@@ -1084,7 +1118,11 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
         return NVDR_ERR_ARG;
     }
     NVDR_REQUIRE(L == 0 || mip, "texture_construct_mip: null mip buffer");
-    for (int l = 1; l <= L; l++) {
+    // levels of at most kMipTailElems elements form the tail (one launch); the larger ones get a launch each
+    int tail = L + 1;
+    while (tail > 1 && (long long)lw[tail - 1] * lh[tail - 1] * depth * C <= kMipTailElems) tail--;
+    if (tail == L) tail = L + 1;                                              // a tail of one level gains nothing
+    for (int l = 1; l < tail && l <= L; l++) {
         MipParams mp;
         mp.in = (l == 1) ? tex : mip + off[l - 1];
         mp.out = mip + off[l];
@@ -1092,6 +1130,14 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
         const long long total_out = (long long)mp.wo * mp.ho * depth * C;
         ProfileScope ps("tex_mip_build", stream);
         hipLaunchKernelGGL(k_mip_build, dim3((unsigned)((total_out + 255) / 256)), dim3(256), 0, stream, mp);
+    }
+    if (tail <= L) {
+        MipTailParams tp;
+        tp.in = (tail == 1) ? tex : mip + off[tail - 1];
+        tp.mip = mip; tp.first = tail; tp.last = L; tp.depth = depth; tp.C = C;
+        for (int l = 0; l <= L; l++) { tp.off[l] = off[l]; tp.w[l] = lw[l]; tp.h[l] = lh[l]; }
+        ProfileScope ps("tex_mip_build", stream);
+        hipLaunchKernelGGL(k_mip_build_tail, dim3(1), dim3(1024), 0, stream, tp);
     }
     NVDR_LAUNCH_CHECK();
     return NVDR_OK;
