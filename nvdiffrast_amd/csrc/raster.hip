@@ -10,26 +10,31 @@
 //            record per surviving (sub)triangle: three edge functions in "pixel form"
 //            E(X,Y) = C + X*A + Y*B (fill rule folded into C), the depth plane, the id
 //            and a packed tile AABB; records and AABBs are staged in LDS and leave as whole
-//            rows.  Clipped triangles are queued and set up densely in a second pass; their
-//            sub-triangles take slots from a per-image pool sized for the worst case (7 per
-//            triangle), so nothing can overflow and the host never synchronises (the
-//            reference retries after a D2H copy, RasterImpl.cpp:174-231,367).  Per-bin
-//            triangle counts and slot ranges are accumulated in an LDS histogram.
+//            rows.  Triangles crossing a frustum plane are queued and clipped densely in a second
+//            pass (once each, polygon buffers in LDS); their sub-triangles take slots from a
+//            per-image pool -- sized for the worst case (7 per triangle) while that is affordable,
+//            so nothing can overflow and the host never synchronises (the reference retries after
+//            a D2H copy, RasterImpl.cpp:174-231,367), else grown on demand by the caller.
+//            Per-bin triangle counts and slot ranges are accumulated in an LDS histogram.
 //  k_order   heavy-first work order of the (image, bin) items inside each XCD's chunk; last
-//            reader of k_setup's counters, which it leaves zeroed for the next call.
+//            reader of k_setup's counters, which it leaves zeroed for the next call.  In small
+//            launches it also gives the bins with the most triangles extra work items (parts).
 //  k_fine    one workgroup (8 waves) per 64x64-pixel bin.  (1) The waves scan the bin's range
 //            of packed AABBs and compact the triangles that touch the bin into an LDS list
 //            (ballot/mbcnt prefix sums).  (2) The list's (triangle, 8x8 tile) pairs are numbered
 //            by a prefix sum and dealt to the waves 64 at a time, ONE LANE PER PAIR: the lane
 //            walks its triangle's three edge functions over the tile's 64 pixel centres with
-//            integer adds into a 64-bit coverage mask, then pops the set bits and merges
+//            integer adds into a 64-bit coverage mask, then pops the set bits (masks with many
+//            fragments: the whole wave, one lane per pixel, the mask as execution mask) and merges
 //            depth << 32 | ~id into the tile's per-pixel keys with an LDS 64-bit atomic min:
 //            minimum depth wins, ties go to the highest triangle id, which is exactly what
 //            the reference's in-order LEQUAL ROP produces (FineRaster.inl:152-172,349-361)
 //            without needing any ordering.  (3) One lane per pixel: the winning id goes
 //            straight into the pixel shader (rasterize.cu:15-114) in the same kernel, so the
 //            id/depth surfaces never touch HBM (the depth surface is stored only for depth
-//            peeling).
+//            peeling).  A bin shared by several workgroups: every part rasterises its share of the
+//            bin's slot range, the parts' key arrays meet in memory (returning device-scope atomics
+//            only) and the part that arrives last shades.
 //  k_raster_grad  rasterize.cu:119-277; per-pixel gradients (a reverse-mode tape of the pixel
 //            shader) are summed over triangle runs, accumulated per vertex in an LDS fixed-point
 //            hash table per 64x16-pixel block and flushed with one hardware atomic per
