@@ -3,7 +3,8 @@
 // Replaces csrc/common/texture_kernel.cu + csrc/common/texture.cpp + csrc/torch/torch_texture.cpp
 // behind the C ABI (2D textures and cube maps).
 //
-//  k_mip_build   one lane per output texel, 2x2 box filter (texture_kernel.cu:644-699).
+//  k_mip_build   one lane per output texel, 2x2 box filter (texture_kernel.cu:644-699); the small levels at the end
+//                of the chain in one launch of one workgroup (k_mip_build_tail).
 //  k_tex_fwd     one lane per pixel, a wave = one 8x8 pixel tile so that the 4..8 texel taps of
 //                a wave land in a compact texture footprint (L1/L2 hits); uv / uv_da / out are
 //                read and written as whole float2 / float4 per lane.  Tiles are handed to the
@@ -13,7 +14,8 @@
 //                registers first, and only the claimed patches are flushed, with line-coalesced
 //                hardware f32 atomics; uv / uv_da / bias gradients are written per pixel
 //                (texture_kernel.cu:905-1140).
-//  k_mip_grad    one lane per base texel pulls its ancestors' gradients (:843-895).
+//  k_mip_grad    one lane per 4x4 block of base texels pulls the block's ancestors' gradients (:843-895); rows of the
+//                block are accessed as float4 vectors when the channel count allows (k_mip_grad_vec).
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
 
