@@ -660,7 +660,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     constexpr int kCoop = 8;
     const bool big = __popcll(m) > kCoop;
     uint64_t heavy = __ballot(big);
-    if (__ballot(!big && m != 0)) {
+    if (__ballot(!big && m != 0) && !(DBG && (p.dbg & 8192))) {
         const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
         unsigned long long* keys = sh.key[tyl][tx];
         // Start each lane at a different bit so that equal masks do not all hit one LDS address.
@@ -678,12 +678,13 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
                     uint32_t pz = p.peel[((size_t)n * p.Hp + (Y0 + (int)y + p.vp.offy)) * p.Wp + (X0 + (int)x + p.vp.offx)];
                     live = depth > pz;                                               // FineRaster.inl:349
                 }
-                if (live) atomicMin(&keys[y * 8 + x], ((unsigned long long)depth << 32) | idk);
+                if (DBG && (p.dbg & 2048)) { if (depth == 0x12345u) keys[y * 8 + x] = depth; }            // experiment: the loop without its atomics
+                else if (live) atomicMin(&keys[y * 8 + x], ((unsigned long long)depth << 32) | idk);
             }
         }
     }
     const uint32_t m0lo = (uint32_t)m, m0hi = (uint32_t)(m >> 32);
-    if (heavy) {
+    if (heavy && !(DBG && (p.dbg & 4096))) {
         const uint32_t xl = 7u - (uint32_t)(lane & 7), yl = 7u - (uint32_t)(lane >> 3);       // this lane's pixel: bit `lane` of a mask
         unsigned long long* keys0 = &sh.key[0][0][0];
         do {
@@ -1408,7 +1409,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         // fewer bins than two rounds of resident workgroups the launch is as long as its heaviest bin (batch 16 at
         // 512^2: k_fine 91 -> 57 us); with more, the helpers' extra list building costs more than the shorter tail
         // gains (batch 64: 126 -> 130 us).
-        const bool dbgMode = debug_buffer() != nullptr || (debug_flags() & (4 | 8 | 16 | 128 | 256 | 512)) != 0;
+        const bool dbgMode = debug_buffer() != nullptr || (debug_flags() & (4 | 8 | 16 | 128 | 256 | 512 | 2048 | 4096 | 8192)) != 0;
         const bool split = !dbgMode && totalBins <= 2 * resident_fine_workgroups() && !(debug_flags() & 1048576);
         const int splitTris = split ? kSplitTris : 0x7FFFFFFF, splitPart = kSplitPart;
         {
