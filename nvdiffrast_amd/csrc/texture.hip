@@ -672,7 +672,9 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         if (slot >= 0) atomicAdd(&tab.vals[slot * C + c], fs.to_fixed(v));
     };
     auto spill = [&](int slot, int level, int tc, int c, float v) {
-        if (tc >= 0 && slot < 0) atomic_add_f32(p.gradTex[level] + tc * C + c, v);
+        // (the level number is laundered through an empty asm: otherwise the 64-bit ADDRESS of the table entry is kept
+        //  live across the whole scatter -- and, there being no register for it, parked in scratch -- for this rare path)
+        if (tc >= 0 && slot < 0) { int lv = level; asm volatile("" : "+v"(lv)); atomic_add_f32(p.gradTex[lv] + tc * C + c, v); }
     };
     auto slots_of = [&](const Quad& q, int level, int* sl) {
         // The four taps of a bilinear footprint share patches most of the time: look each patch up once.
