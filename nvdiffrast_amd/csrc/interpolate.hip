@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
         const RunScan rs(q[r].tri, ok[r]);
         const bool emit = direct ? ok[r] : rs.tail;
         int s0 = -1, s1 = -1, s2 = -1;
-        if (emit && !direct) { s0 = tab.find(vi[r][0]); s1 = tab.find(vi[r][1]); s2 = tab.find(vi[r][2]); }
+        if (emit && !direct) tab.find3(vi[r][0], vi[r][1], vi[r][2], s0, s1, s2);
         // Lanes whose three vertices all have slots (the rule) add to the table under ONE test per value triple;
         // the rest (table full, inf/NaN mode) take the per-vertex path under a wave-uniform test.
         const bool tabled = emit && (s0 | s1 | s2) >= 0;

@@ -292,6 +292,30 @@ struct VertexTable {
         }
         return -1;
     }
+    // The same for three vertices at once: the three first probes are in flight together (one LDS round trip instead of
+    // three); only a probe that lands on another vertex's slot continues on its own.
+    __device__ __forceinline__ void find3(int va, int vb, int vc, int& sa, int& sb, int& sc) const {
+        const uint32_t ka = (uint32_t)va + 1u, kb = (uint32_t)vb + 1u, kc = (uint32_t)vc + 1u;
+        const uint32_t ha = ((ka * 0x9E3779B1u) >> 8) & (uint32_t)(slots - 1);
+        const uint32_t hb = ((kb * 0x9E3779B1u) >> 8) & (uint32_t)(slots - 1);
+        const uint32_t hc = ((kc * 0x9E3779B1u) >> 8) & (uint32_t)(slots - 1);
+        const uint32_t oa = atomicCAS(&keys[ha], 0u, ka);
+        const uint32_t ob = atomicCAS(&keys[hb], 0u, kb);
+        const uint32_t oc = atomicCAS(&keys[hc], 0u, kc);
+        sa = (oa == 0u || oa == ka) ? (int)ha : probe_on(ka, ha + 1u);
+        sb = (ob == 0u || ob == kb) ? (int)hb : probe_on(kb, hb + 1u);
+        sc = (oc == 0u || oc == kc) ? (int)hc : probe_on(kc, hc + 1u);
+    }
+    __device__ __forceinline__ int probe_on(uint32_t key, uint32_t h) const {
+#pragma unroll 1
+        for (int probe = 1; probe < 16; probe++) {
+            h &= (uint32_t)(slots - 1);
+            const uint32_t old = atomicCAS(&keys[h], 0u, key);
+            if (old == 0u || old == key) return (int)h;
+            h++;
+        }
+        return -1;
+    }
     __device__ __forceinline__ void add(int slot, int comp, unsigned long long v) const {
         atomicAdd(&vals[slot * stride + comp], v);
     }

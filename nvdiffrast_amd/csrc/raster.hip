@@ -1228,9 +1228,11 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
         for (int k = 0; k < 9; k += 3) rs.scan3(pg[r].g[k], pg[r].g[k + 1], pg[r].g[k + 2]);
         if (rs.tail) {
             const int vi[3] = {pg[r].vi0, pg[r].vi1, pg[r].vi2};
+            int sl[3];
+            tab.find3(vi[0], vi[1], vi[2], sl[0], sl[1], sl[2]);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const int s = tab.find(vi[k]);
+                const int s = sl[k];
                 if (s >= 0) {
                     tab.add(s, 0, fs.to_fixed(pg[r].g[k * 3 + 0]));
                     tab.add(s, 1, fs.to_fixed(pg[r].g[k * 3 + 1]));
