@@ -22,6 +22,7 @@ struct InterpParams {
     int numTriangles, numVertices, numAttr, numDiffAttr;
     int width, height, depth;
     int attrBC, instance_mode, diff_attrs_all, dbg;
+    int streamOut;          // forward: the output is too large to stay in the Infinity Cache anyway -> non-temporal stores
     int diffAttrs[kMaxDiffAttrs];
 };
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 
     if (!valid) {
         // No triangle: zeros (the reference reaches the same values via zero barycentrics, :73-80).
-        if (A_CT == 4)      *(float4*)out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (A_CT == 4)      { if (p.streamOut) store_streaming((float4*)out, make_float4(0.f, 0.f, 0.f, 0.f)); else *(float4*)out = make_float4(0.f, 0.f, 0.f, 0.f); }
         else if (A_CT == 2) *(float2*)out = make_float2(0.f, 0.f);
         else for (int i = 0; i < A; i++) out[i] = 0.f;
         if (ENABLE_DA) for (int i = 0; i < p.numDiffAttr; i++) outDA[i] = make_float2(0.f, 0.f);
@@ -74,8 +75,9 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 
     if (A_CT == 4) {
         float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
-        *(float4*)out = make_float4(b0 * x0.x + b1 * x1.x + b2 * x2.x, b0 * x0.y + b1 * x1.y + b2 * x2.y,
-                                    b0 * x0.z + b1 * x1.z + b2 * x2.z, b0 * x0.w + b1 * x1.w + b2 * x2.w);
+        const float4 o = make_float4(b0 * x0.x + b1 * x1.x + b2 * x2.x, b0 * x0.y + b1 * x1.y + b2 * x2.y,
+                                     b0 * x0.z + b1 * x1.z + b2 * x2.z, b0 * x0.w + b1 * x1.w + b2 * x2.w);
+        if (p.streamOut) store_streaming((float4*)out, o); else *(float4*)out = o;
     } else if (A_CT == 2) {
         float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
         *(float2*)out = make_float2(b0 * x0.x + b1 * x1.x + b2 * x2.x, b0 * x0.y + b1 * x1.y + b2 * x2.y);
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
 
         float gb0 = 0.f, gb1 = 0.f, ymax = 0.f;
         if (A_CT == 4) {
-            const float4 y = *(const float4*)pdy;
+            const float4 y = load_streaming((const float4*)pdy);      // read once per step: keep it out of the Infinity Cache
             const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
             gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
             gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
@@ -361,6 +363,9 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
     NVDR_REQUIRE(!enable_da || out_da, "interpolate_fwd: out_da missing");
     NVDR_REQUIRE(!((uintptr_t)out_da & 7), "out_da output tensor not aligned to float2");
     p.out = out; p.outDA = enable_da ? out_da : nullptr;
+    // An output larger than most of the 256 MB Infinity Cache cannot be found there by its consumer anyway; written
+    // around the cache it leaves `rast` (read again by the backward kernels) in place.
+    p.streamOut = ((size_t)N * H * W * A * sizeof(float) > ((size_t)192 << 20)) ? 1 : 0;
     NVDR_REQUIRE((long long)H * W < (1ll << 31), "interpolate_fwd: image too large");
     dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)(N < 32768 ? N : 32768), (unsigned)((N + 32767) / 32768)), block(256);
     const float* VECPTR = out;
