@@ -21,6 +21,7 @@ def _run(*flags):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                       # rank 0 only
+    assert r.stdout.strip() == lines[0], r.stdout          # and nothing else on stdout (everything else goes to stderr)
     return json.loads(lines[0])
 
 

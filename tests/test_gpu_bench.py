@@ -22,6 +22,7 @@ def _bench(*flags):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
+    assert r.stdout.strip() == lines[0], r.stdout          # RCCL's banner and everything else must be on stderr
     return json.loads(lines[0])
 
 
