@@ -35,7 +35,14 @@ unsigned long long* debug_buffer() { return g_dbgbuf; }
 
 int debug_flags() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("NVDR_DEBUG"); v = e ? atoi(e) : 0; }
+    if (v < 0) {
+        const char* e = getenv("NVDR_DEBUG");
+        v = e ? atoi(e) : 0;
+        // Development switches change which kernels run (some skip work altogether): never silently.
+        if (v != 0 && g_options[NVDR_OPT_LOG_LEVEL] <= 1)
+            fprintf(stderr, "[nvdr] WARNING: NVDR_DEBUG=%d is set: development switches are active, results and timings are "
+                            "not those of the product path\n", v);
+    }
     return v;
 }
 

@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
             if (threadIdx.x == 0 && s_poolNeed > 0) s_poolBase = atomicAdd(&p.poolCount[n], s_poolNeed);
             __syncthreads();
             if (act) clip_emit(p, n, ci, st, ns, id, s_hist, s_poolBase + poolOff);
+            __syncthreads();                                 // every lane has read s_poolBase before the next round resets it
         }
     }
     __syncthreads();
@@ -959,9 +960,24 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
         for (int tt = 0; tt < kTilesPerWave; tt++)
             seen |= atomicExch(&gkeys[part * 4096 + tt * 64], sh.key[tileRow][tile0 + tt][laneS]);
+        // EVERY wave waits here, before the barrier, until the old values of its exchanges have come back: a returned
+        // value is the proof that the exchange has been performed at the memory side.  (Left to the compiler, the wait
+        // sank below the barrier -- the values are only consumed after it -- so that seven of the eight waves could pass
+        // the barrier, and thread 0 count the part in, with their keys still in flight: ADVICE r2.  The ISA of this
+        // instantiation is checked by tests/test_kernel_resources.py.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int landed = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(seen == 1ull)));      // consumes every returned value (whatever it is)
         __syncthreads();
-        if (threadIdx.x == 0) sh.count = (atomicAdd(&p.splitDone[split], 1 + (landed >> 8)) == parts - 1) ? 1 : 0;
+        // The arrival counter carries the hand-off in the memory model's terms as well: release (this part's keys are
+        // visible before its count) and acquire (the last part sees the others' keys after reading the full count), at
+        // agent scope, by ONE thread of the shared bins' workgroups only -- not the per-wave fences in every workgroup
+        // that cost 126 -> 220 us in round 2.  NVDR_DEBUG bit 4194304 selects the relaxed form (timing comparison).
+        if (threadIdx.x == 0) {
+            const int add = 1 + (landed >> 8);
+            const int before = (p.dbg & 4194304) ? atomicAdd(&p.splitDone[split], add)
+                                                 : __hip_atomic_fetch_add(&p.splitDone[split], add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            sh.count = (before == parts - 1) ? 1 : 0;
+        }
         __syncthreads();
         if (!sh.count) return;
     }

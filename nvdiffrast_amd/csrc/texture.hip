@@ -983,14 +983,29 @@ __global__ __launch_bounds__(256) void k_mip_build(const MipParams p)
 // ONE launch of one workgroup: a launch per level is 6-8 us of latency for microseconds of work.
 struct MipTailParams { const float* in; float* mip; long long off[kTexMaxLevels]; int w[kTexMaxLevels], h[kTexMaxLevels]; int first, last, depth, C; };
 
-constexpr int kMipTailElems = 12288;                       // largest level of the tail (elements = texels x channels x slices)
+constexpr int kMipTailElems  = 12288;                      // capacity of the tail's first level (elements = texels x channels x slices)
+constexpr int kMipTailElems2 = kMipTailElems / 4;          // ... and of its second level
+
+// First level of the tail: the earliest l such that level l fits the first LDS buffer and level l + 1 (if any) the
+// second; L + 1 = no tail.  Thin textures (one extent already 1) halve per level instead of quartering, so their tail
+// starts later than that of a square texture with the same element count.
+static int mip_tail_start(const int* lw, const int* lh, int L, long long per_texel)
+{
+    auto elems = [&](int l) { return (long long)lw[l] * lh[l] * per_texel; };
+    int tail = 1;
+    while (tail <= L && !(elems(tail) <= kMipTailElems && (tail == L || elems(tail + 1) <= kMipTailElems2))) tail++;
+    if (tail >= L) tail = L + 1;                              // a tail of one level gains nothing
+    return tail;
+}
 
 __global__ __launch_bounds__(1024) void k_mip_build_tail(const MipTailParams q)
 {
-    // Every level is written to memory AND kept in LDS for the next one (a level is a quarter of the one before, so
-    // two buffers alternate): no memory round trip between the levels.
+    // Every level is written to memory AND kept in LDS for the next one, two buffers alternating: no memory round trip
+    // between the levels.  A level is a quarter of the one before while both extents shrink but only HALF of it once one
+    // extent has reached 1 (texture.cpp:77-98), so the host admits a chain into the tail only if its first level fits
+    // s_a and its second fits s_b (tail_start); every later level is at most half of the level two steps before it.
     __shared__ float s_a[kMipTailElems];
-    __shared__ float s_b[kMipTailElems / 4];
+    __shared__ float s_b[kMipTailElems2];
     for (int l = q.first; l <= q.last; l++) {
         float* keep = ((l - q.first) & 1) ? s_b : s_a;
         const float* prev = ((l - q.first) & 1) ? s_a : s_b;
@@ -1232,10 +1247,8 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
         return NVDR_ERR_ARG;
     }
     NVDR_REQUIRE(L == 0 || mip, "texture_construct_mip: null mip buffer");
-    // levels of at most kMipTailElems elements form the tail (one launch); the larger ones get a launch each
-    int tail = L + 1;
-    while (tail > 1 && (long long)lw[tail - 1] * lh[tail - 1] * depth * C <= kMipTailElems) tail--;
-    if (tail == L) tail = L + 1;                                              // a tail of one level gains nothing
+    // the small levels at the end of the chain form the tail (one launch); the larger ones get a launch each
+    const int tail = mip_tail_start(lw, lh, L, (long long)depth * C);
     for (int l = 1; l < tail && l <= L; l++) {
         MipParams mp;
         mp.in = (l == 1) ? tex : mip + off[l - 1];

@@ -255,6 +255,8 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
         worst = state.scratch_bytes(lib, depth, max_tri, height, width, -1)
         adaptive = worst > (int(lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB)) << 20)
         pool = state.pool_hint(depth, max_tri) if adaptive else -1
+        worst_pool = 6 * max_tri                 # the clipper's worst case: a pool this large cannot overflow and the library
+        #                                          neither clears nor writes the demand counter for it (include/nvdr_hip.h)
         if adaptive and _is_capturing(dev):
             _fail(fn, "this call needs %d MB of worst-case rasterizer scratch, above the NVDR_OPT_SCRATCH_LIMIT_MB limit; the "
                       "growing clip pool used instead reads a counter back after each call and cannot be captured into a "
@@ -268,13 +270,16 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
                                         _capi.ptr(peel_in), _capi.ptr(depth_out),
                                         scratch.data_ptr(), scratch.numel(), int(clean), pool,
                                         out.data_ptr(), out_db.data_ptr(), _stream(dev))
-            if rc != 0 or not adaptive:
-                break
+            if rc != 0 or not adaptive or pool < 0 or pool >= worst_pool:
+                break                                                        # (worst-case pool: nothing to read back)
             off = lib.nvdr_rasterize_pool_peak_offset(depth, max_tri, height, width, pool)
             need = int(scratch[off:off + 4].view(torch.int32).item())        # the one host synchronisation of this mode
             if need <= pool:
                 break
-            pool = state.grow_pool(depth, max_tri, need)
+            grown = state.grow_pool(depth, max_tri, need)
+            if grown <= pool:                                                # cannot happen (need <= 6 * max_tri): never spin
+                _fail(fn, "clip pool demand %d exceeds the worst case of %d slots per image" % (need, worst_pool))
+            pool = grown
             _log_info("Clip pool grown to %d sub-triangle slots per image" % pool)
     _capi.check(rc, fn)
     state.mark_clean(layout)

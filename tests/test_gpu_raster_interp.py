@@ -223,3 +223,33 @@ def test_bins_shared_by_several_workgroups(dr, oracle):
             got_depth = ctx.cpp_wrapper.depth.cpu().numpy().view(np.uint32)[:, :res[0], :res[1]]
             cov = want[..., 3] > 0
             assert (got_depth[cov] != np.asarray(depth).view(np.uint32)[:, :res[0], :res[1]][cov]).sum() == 0, "layer %d depth" % k
+
+
+def test_shared_bins_stress_with_poisoned_exchange_buffers(dr, oracle):
+    """200 calls through the shared-bin path: four strip scenes in rotation, the exchange buffers
+    overwritten with zeros before every call (a stale key of 0 would win every minimum, so a part that read keys before
+    their owner had published them shows up as a wrong id), and unrelated work on a second stream to vary which part of a
+    bin arrives last.  Ids identical to the oracle's in every call."""
+    scenes = []
+    for k, squeeze in enumerate((0.04, 0.025, 0.06, 0.035)):
+        b = m10k_batch(2, seed=40 + k)
+        pos = b["pos"].copy()
+        pos[..., k % 2] *= squeeze                          # vertical and horizontal strips
+        ro, _ = oracle.rasterize(pos, b["tri"], (512, 512))
+        scenes.append((_t(pos), _t(b["tri"]), _t(ro[..., 3].copy())))
+    ctx = dr.RasterizeCudaContext()
+    side = torch.cuda.Stream()
+    noise = torch.empty(1 << 22, device="cuda")
+    bad = 0
+    for it in range(200):
+        pos, tri, want = scenes[it % 4]
+        if ctx.cpp_wrapper.scratch is not None:
+            ctx.cpp_wrapper.scratch.zero_()
+            ctx.cpp_wrapper.clean_layout = None
+        with torch.cuda.stream(side):
+            for _ in range(it % 5):
+                noise.add_(1.0)
+        r, _ = dr.rasterize(ctx, pos, tri, (512, 512))
+        bad += int((r[..., 3] != want).sum().item())
+    torch.cuda.synchronize()
+    assert bad == 0

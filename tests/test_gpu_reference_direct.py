@@ -212,3 +212,40 @@ def test_growing_clip_pool_gives_the_same_image(dr, oracle, capfd):
     finally:
         lib.nvdr_set_option(_capi.OPT_SCRATCH_LIMIT_MB, old)
         _plugin.set_log_level(1)
+
+
+def test_growing_pool_mode_with_the_worst_case_pool_does_not_read_garbage(dr, oracle):
+    """in growing-pool mode the glue read the demand counter back even when the pool was already the
+    clipper's worst case (meshes of <= 4096 triangles start there; grow_pool caps there) -- a counter the library neither
+    clears nor writes in that case, so a stale value above the pool made the retry loop spin for ever.  The buffer is
+    poisoned first so that a read of the counter would see such a value."""
+    from nvdiffrast_amd import _capi
+    rng = np.random.default_rng(13)
+    T = 500
+    pos = rng.normal(size=(3, 3 * T, 4)).astype(np.float32) * np.array([3.0, 3.0, 1.5, 1.0], np.float32)
+    pos[..., 3] = rng.uniform(0.05, 1.5, size=pos.shape[:2])
+    tri = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    ro, _ = oracle.rasterize(pos, tri, (64, 64))
+    lib = _capi.load()
+    old = lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB)
+    lib.nvdr_set_option(_capi.OPT_SCRATCH_LIMIT_MB, 0)
+    try:
+        ctx = dr.RasterizeCudaContext()
+        st = ctx.cpp_wrapper
+        assert st.pool_hint(3, T) == 6 * T
+        nbytes = st.scratch_bytes(lib, 3, T, 64, 64, 6 * T)
+        st.scratch = torch.full((nbytes,), 0x7F, dtype=torch.uint8, device="cuda")      # every int reads 0x7F7F7F7F
+        for _ in range(2):
+            r, _ = dr.rasterize(ctx, _t(pos), _t(tri), (64, 64))
+            assert (r.cpu().numpy()[..., 3] != ro[..., 3]).sum() == 0
+        # a pool that has grown to the cap behaves the same
+        T2 = 6000
+        pos2 = rng.normal(size=(1, 3 * T2, 4)).astype(np.float32) * np.array([3.0, 3.0, 1.5, 1.0], np.float32)
+        pos2[..., 3] = rng.uniform(0.05, 1.5, size=pos2.shape[:2])
+        tri2 = np.arange(3 * T2, dtype=np.int32).reshape(T2, 3)
+        st.pools[(1, T2)] = 6 * T2
+        ro2, _ = oracle.rasterize(pos2, tri2, (64, 64))
+        r2, _ = dr.rasterize(ctx, _t(pos2), _t(tri2), (64, 64))
+        assert (r2.cpu().numpy()[..., 3] != ro2[..., 3]).sum() == 0
+    finally:
+        lib.nvdr_set_option(_capi.OPT_SCRATCH_LIMIT_MB, old)

@@ -113,6 +113,35 @@ def test_mip_construction_and_reuse(dr, oracle):
         dr.texture(torch.zeros(1, 6, 4, 8, 3, device="cuda"), torch.zeros(1, 2, 2, 3, device="cuda"), boundary_mode="cube")
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 4096, 4), (1, 2, 4096, 3), (1, 4096, 1, 4), (2, 2, 2048, 2), (1, 1, 8192, 1),
+                                   (1, 4, 1024, 3), (3, 64, 64, 1), (1, 1, 2, 1), (1, 128, 2, 4)])
+def test_mip_chain_of_thin_textures(dr, oracle, shape):
+    """Once one extent has reached 1 a level is HALF of the one before, not a quarter (texture.cpp:77-98): the launch that
+    builds the small levels at the end of the chain in LDS must size its two buffers for that (1 x 4096 x 4: level 1 has
+    8192 elements, level 2 has 4096).  Every level against the oracle, and the mipmapped sample / gradient through them."""
+    rng = np.random.default_rng(sum(shape))
+    tex = rng.uniform(size=shape).astype(np.float32)
+    w = dr.texture_construct_mip(_t(tex))
+    levels = oracle.texture_build_mip(tex)
+    flat = np.concatenate([l.reshape(-1) for l in levels])
+    assert w.mip.numel() == flat.size
+    got = w.mip.cpu().numpy()
+    off = 0
+    for k, l in enumerate(levels, start=1):
+        assert np.abs(got[off:off + l.size] - l.reshape(-1)).max() <= 1e-6, ("mip level", k, l.shape)
+        off += l.size
+    n = shape[0]
+    uv = rng.uniform(size=(n, 8, 8, 2)).astype(np.float32)
+    bias = rng.uniform(0.0, len(levels), size=(n, 8, 8)).astype(np.float32)
+    t_tex = _t(tex).requires_grad_(True)
+    out = dr.texture(t_tex, _t(uv), None, _t(bias), filter_mode="linear-mipmap-linear")
+    dy = rng.normal(size=tuple(out.shape)).astype(np.float32)
+    out.backward(_t(dy))
+    _close(out.detach().cpu().numpy(), oracle.texture(tex, uv, None, bias, filter_mode="linear-mipmap-linear"), ATOL)
+    g = oracle.texture_grad(tex, uv, dy, None, bias, filter_mode="linear-mipmap-linear")
+    _close(t_tex.grad.cpu().numpy(), g["tex"], _tol(g["tex"]))
+
+
 def test_custom_mip_stack_gradients(dr, oracle):
     rng = np.random.default_rng(9)
     tex = rng.uniform(size=(1, 16, 16, 2)).astype(np.float32)

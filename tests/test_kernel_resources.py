@@ -15,6 +15,20 @@ CSRC = os.path.join(ROOT, "nvdiffrast_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+_ASM = {}
+
+
+def _assembly(tmp_path, src):
+    if src not in _ASM:
+        _metadata(tmp_path, src)
+    return _ASM[src]
+
+
+def _kernel_body(text, mangled):
+    i = text.index(mangled + ":")
+    return text[i:text.index("s_endpgm", i)].split("\n")
+
+
 def _metadata(tmp_path, src):
     out = tmp_path / (src + ".s")
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only",
@@ -22,6 +36,7 @@ def _metadata(tmp_path, src):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     text = out.read_text()
+    _ASM[src] = text
     kernels = {}
     for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text):
         kernels[m.group(1)] = (int(m.group(2)), int(m.group(3)))
@@ -49,3 +64,24 @@ def test_interpolate_kernels_stay_within_their_budgets(tmp_path):
             assert scratch == 0, (name, scratch)
     g4 = [v for n, v in k.items() if "k_interp_gradILi4ELb0E" in n]
     assert g4 and g4[0][1] <= 64, g4                                            # 8 waves/SIMD, 8 workgroups/CU
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_shared_bin_handoff_waits_for_its_exchanges_before_the_barrier(tmp_path):
+    """a part of a shared bin publishes its keys with returning exchanges and may count itself in only when
+    the old values have come back in EVERY wave.  The compiler had sunk that wait below the workgroup barrier (the
+    values are consumed after it).  Every k_fine<..., SPLIT> instantiation must have `s_waitcnt vmcnt(0)` between its
+    last global_atomic_swap and the barrier that follows, and the arrival counter must be a release/acquire pair."""
+    text = _assembly(tmp_path, "raster.hip")
+    names = re.findall(r"^(_ZN4nvdr6k_fineILb[01]ELb[01]ELb0ELb1EEEvNS_10FineParamsE):", text, flags=re.M)
+    assert len(names) == 4, names
+    for name in names:
+        body = _kernel_body(text, name)
+        swaps = [i for i, l in enumerate(body) if "global_atomic_swap_x2" in l]
+        assert len(swaps) == 8, (name, len(swaps))
+        barrier = next(i for i in range(swaps[-1], len(body)) if "s_barrier" in body[i])
+        between = [l.strip() for l in body[swaps[-1] + 1:barrier]]
+        assert "s_waitcnt vmcnt(0)" in between, (name, between)
+        add = next(i for i in range(barrier, len(body)) if "buffer_wbl2" in body[i])
+        window = " ".join(l.strip() for l in body[add:add + 5])
+        assert "global_atomic_add" in window and "buffer_inv" in window, (name, window)
