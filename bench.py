@@ -21,15 +21,25 @@ With N > 1 the step also contains the path's two exchanges (north_star; SURVEY 8
 output images to every rank -- issued per chunk of items on RCCL's stream while the next chunk is being rendered
 (`--chunks`, `--no-gather-images`) -- and the all-reduce of the gradient of the SHARED vertex attributes.
 
+Timing: after W warm-up steps, `--windows` (default 5) windows of EXACTLY K steps each, every window bracketed by
+barrier + synchronize on both sides and timed with the host clock (max over ranks) and with a hipEvent pair;
+`ms_per_step` is the MEDIAN window, `ms_per_step_min/max` the spread (median over event pairs).
+
 Rank 0 prints ONE JSON line.  Beside the headline number it carries
-  roofline      the LONGEST kernel of the step (hipEvents recorded by the library on the launch stream): algorithmic
-                bytes / time against the 8 TB/s HBM peak, the PMC-measured HBM traffic if profiles/traffic.json has it;
+  roofline      the LONGEST kernel of the step (hipEvents recorded by the library on the launch stream):
+                `frac` = ALGORITHMIC bytes / time / 8 TB/s (SURVEY 8(d)'s convention: compulsory tensor traffic, whether or
+                not a kernel can skip part of it); `traffic` = the PMC-measured HBM bytes of that kernel per launch, taken
+                from profiles/traffic.json (a builder-session rocprofv3 measurement, named in `traffic_source` -- NOT
+                measured in this run); `hbm_frac_counter` = traffic / time / peak = the physically moved bytes' rate;
   path_hbm_frac the whole step's algorithmic bytes / step time against the same peak;
   cpu_baseline  the CPU oracle (a port of the reference's algorithm -- the reference has no CPU path) on this box's
                 host cores, bounded sample; cpu_reference = the reference's own kernels under the CUDA-on-CPU shim
                 of oracle/refshim (one thread), when oracle/_ref is present;
   parity        id mismatches / max-abs errors of this very workload against the reference itself (oracle/_ref) when
-                present, else against the oracle.
+                present, else against the oracle;
+  configs       (default single-GPU run only) BASELINE configs[1], [2] and the [4] stand-in measured in the same process:
+                per config ms_per_step (median of windows), per-kernel times, roofline of its longest kernel and a parity
+                block of that very workload at its full resolution (`--no-extra-configs` leaves them out).
 `--dry-run-cpu` replaces the kernels by a stand-in and RCCL by gloo so that the launch / collective / timing
 plumbing can be exercised on a machine without GPUs (tests/test_bench_spawn.py); its line says "dry_run": true.
 """
@@ -49,10 +59,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 XGMI_LINK_GBS = 153.0          # per direction per link; 7 links per GPU, fully connected (task statement / SURVEY 8e)
+HOST_MS_PER_CHUNK = 0.20       # measured host cost of issuing one chunk's six launches eagerly
 TRIANGLES = 10000
 
 WORKLOADS = {
-    # name: (items per GPU or None, total items or None, resolution, graph, scaling, attrs)
     "ch": dict(per_gpu=64, total=None, res=512, graph="ri", scaling="weak", attrs=4,
                metric="Mpixels/s rasterize+interpolate fwd+bwd @512^2 batch64"),
     "c2": dict(per_gpu=16, total=None, res=512, graph="ri", scaling="weak", attrs=4,
@@ -74,6 +84,7 @@ def algorithmic_bytes(graph, P, A, T, N):
             "interp_fwd": (16 + 4 * A) * P,                     # R rast, W out
             "interp_grad": (4 * A + 16 + 16) * P,               # R dy, R rast, W g_rast
             "raster_grad": 32 * P,                              # R g_rast 16 + R rast 16
+            "interp_raster_grad": (4 * A + 16) * P,             # fused backward: R dy, R rast (g_rast never exists)
         }
         return per_kernel, (112 + 8 * A) * P
     C = 3
@@ -113,6 +124,52 @@ def respawn_under_launcher(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def plan_chunks(n_items, item_bytes, compute_ms, links):
+    """Chunk count of a rank's step when the per-item images are all-gathered inside it.
+
+    The gather's duration does not depend on the chunking: every link carries one peer's images, G = n_items * item_bytes /
+    link bandwidth.  What chunking changes is how early the first gather can START -- after the first chunk's forward
+    kernels, C / (2c) into the step -- against the host's launch work, which bounds a chunk from below (a chunk whose
+    kernels are shorter than the host's ~0.2 ms of launch calls makes the step host-bound).  Model of the step:
+        t(c) = max(C, c * h, first_forward(c) + G),   first_forward(c) = max(C / (2 c), h / 2)
+    and the smallest c within 2 % of the minimum is taken (c <= 8, c <= n_items)."""
+    if links <= 0:
+        return 1, None
+    G = n_items * item_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+    h = HOST_MS_PER_CHUNK
+    best = None
+    table = {}
+    for c in range(1, max(1, min(8, n_items)) + 1):
+        t = max(compute_ms, c * h, max(compute_ms / (2 * c), h / 2) + G)
+        table[c] = round(t, 4)
+        if best is None or t < best[1] * 0.98:
+            best = (c, t)
+    return best[0], {"gather_floor_ms": round(G, 4), "compute_ms_assumed": round(compute_ms, 4), "host_ms_per_chunk": h,
+                     "predicted_step_ms_by_chunks": table}
+
+
+def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduce_ms=0.03):
+    """What the 1/2/4/8-GPU curve must look like from the link arithmetic alone: whole-job speed-up over
+    one GPU with the image all-gather inside the step (every rank receives (N-1) x its own image bytes, one peer per
+    link: floor = own bytes / 153 GB/s, whatever N) and without it (independent ranks + one small all-reduce)."""
+    out = {"with_image_gather": {}, "without_image_gather": {}, "assumes": "compute = %.4f ms per item (this run), "
+           "xGMI link %.0f GB/s at 100 %% efficiency, %.0f us for the shared-gradient all-reduce" % (ms_per_item, XGMI_LINK_GBS, allreduce_ms * 1e3)}
+    items1 = per_gpu if scaling == "weak" else total
+    t1 = items1 * ms_per_item
+    for n in (1, 2, 4, 8):
+        items = per_gpu if scaling == "weak" else -(-total // n)
+        job_items = items * n if scaling == "weak" else total
+        C = items * ms_per_item
+        G = items * item_bytes / (XGMI_LINK_GBS * 1e9) * 1e3 if n > 1 else 0.0
+        ar = allreduce_ms if n > 1 else 0.0
+        c, _ = plan_chunks(items, item_bytes, C, n - 1)
+        t_g = max(C, c * HOST_MS_PER_CHUNK if n > 1 else 0.0, (max(C / (2 * c), HOST_MS_PER_CHUNK / 2) + G) if n > 1 else C) + ar
+        t_n = C + ar
+        out["with_image_gather"][str(n)] = round((job_items / t_g) / (items1 / t1), 2)
+        out["without_image_gather"][str(n)] = round((job_items / t_n) / (items1 / t1), 2)
+    return out
+
+
 class DryKernels:
     """Stand-in for the HIP path in --dry-run-cpu: same tensor shapes, trivial arithmetic, autograd intact."""
 
@@ -125,19 +182,359 @@ class DryKernels:
         return base.expand(n, res, res, A).contiguous()
 
 
+class Job:
+    """One workload on this rank: its tensors resident in device memory and the step the timed region repeats."""
+
+    def __init__(self, name, N, total_items, first, rank, world, dev, dry, res, distributed, chunks, gather):
+        import torch.distributed as dist
+        from nvdiffrast_amd.parallel import broadcast_shared
+        from nvdiffrast_amd.utils import m10k_batch
+        self.dist = dist
+        self.name, self.wl = name, WORKLOADS[name]
+        self.N, self.total_items, self.rank, self.world, self.dev, self.dry = N, total_items, rank, world, dev, dry
+        self.RES = res
+        self.A = self.wl["attrs"]
+        self.full = self.wl["graph"] == "full"
+        self.distributed, self.gather_on = distributed, gather
+        # Per-item poses differ across ranks; geometry every item shares (tri, attr/uv, texture) comes from rank 0 over
+        # RCCL, as it would in a data-parallel job.
+        if dry:
+            self.scene = m10k_batch(N, seed=20240, attrs=self.A, nx=8, ny=4, pose_seed=20240 + 1000 * rank)
+        else:
+            self.scene = m10k_batch(N, seed=20240, attrs=self.A, pose_seed=20240 + 1000 * rank)
+        sc = self.scene
+        self.pos = torch.from_numpy(sc["pos"]).to(dev).requires_grad_(True)
+        self.tri = torch.from_numpy(sc["tri"]).to(dev)
+        self.shared = torch.from_numpy(sc["uv"] if self.full else sc["attr"]).to(dev)
+        self.C_out = 3 if self.full else self.A
+        self.tex = self.tex_np = None
+        if self.full:
+            tex_res = 2048 if not dry else 32
+            self.tex_np = np.random.default_rng(5).uniform(size=(1, tex_res, tex_res, 3)).astype(np.float32)
+            self.tex = torch.from_numpy(self.tex_np).to(dev)
+        if distributed:
+            broadcast_shared([self.tri, self.shared] + ([self.tex] if self.full else []), src=0)
+        self.shared.requires_grad_(True)
+        if self.full:
+            self.tex.requires_grad_(True)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(77 + rank)
+        self.G = torch.randn((N, res, res, self.C_out), generator=gen, device=dev, dtype=torch.float32)
+        if dry:
+            self.impl = DryKernels(dev)
+            self.dr = self.ctx = self.topo = self.lib = None
+        else:
+            import nvdiffrast_amd.torch as dr
+            from nvdiffrast_amd import _capi
+            self.dr, self._capi = dr, _capi
+            self.lib = _capi.load()
+            self.ctx = dr.RasterizeCudaContext(device=dev)
+            self.topo = dr.antialias_construct_topology_hash(self.tri) if self.full else None
+        self.set_chunks(chunks)
+        self.last_rast = None
+
+    def set_chunks(self, chunks):
+        self.chunks = max(1, min(int(chunks), self.N))
+        self.bounds = [(self.N * c // self.chunks, self.N * (c + 1) // self.chunks) for c in range(self.chunks)]
+        self.gathered = [None] * self.chunks                          # receive buffers, reused every step
+
+    def render(self, p):
+        """Forward of the op graph for the items `p` [n,V,4] -> (output image [n,H,W,C], rast)."""
+        dr, res = self.dr, self.RES
+        if self.dry:
+            return self.impl.forward(p, self.shared, res, self.C_out), None
+        rast, rast_db = dr.rasterize(self.ctx, p, self.tri, (res, res))
+        if not self.full:
+            out, _ = dr.interpolate(self.shared, rast, self.tri)
+            return out, rast
+        uv, uv_da = dr.interpolate(self.shared, rast, self.tri, rast_db=rast_db, diff_attrs="all")
+        col = dr.texture(self.tex, uv, uv_da, filter_mode="linear-mipmap-linear")
+        return dr.antialias(col, rast, p, self.tri, topology_hash=self.topo), rast
+
+    def step(self):
+        from nvdiffrast_amd.parallel import allreduce_shared_grads, gather_items_async
+        self.pos.grad = None
+        self.shared.grad = None
+        if self.full:
+            self.tex.grad = None
+        pending = []
+        for c, (a, b) in enumerate(self.bounds):
+            p = self.pos if self.chunks == 1 else self.pos[a:b]
+            out, rast = self.render(p)
+            if self.gather_on:
+                # the collective runs on RCCL's own stream, ordered after this chunk's kernels; the next chunk's
+                # kernels are issued right away and overlap it
+                work, self.gathered[c] = gather_items_async(out.detach(), out=self.gathered[c])
+                pending.append(work)
+            torch.autograd.backward(out, self.G if self.chunks == 1 else self.G[a:b])
+            self.last_rast = rast
+        if self.distributed:
+            allreduce_shared_grads([self.shared] + ([self.tex] if self.full else []))
+        for w in pending:
+            w.wait()
+
+    def fence(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def timed_windows(self, run, warmup, steps, windows):
+        """`windows` windows of exactly `steps` steps, each bracketed by barrier + synchronize on both sides.
+        Returns (host seconds per window, MAX over ranks; hipEvent milliseconds per window of this rank)."""
+        for _ in range(warmup):
+            run()
+        host, evt = [], []
+        for _ in range(windows):
+            self.fence()
+            if not self.dry:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            if not self.dry:
+                e1.record()
+            self.fence()
+            el = time.perf_counter() - t0
+            if self.distributed:
+                tt = torch.tensor([el], dtype=torch.float64, device=self.dev)
+                self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+                el = float(tt.item())
+            host.append(el)
+            evt.append(float(e0.elapsed_time(e1)) if not self.dry else el * 1e3)
+        return host, evt
+
+    # ---- everything below runs on rank 0 after the timed region -----------------------------------------------------
+
+    def coverage(self):
+        """Fraction of the pixels of the last step that a triangle covers (kernels may skip upstream gradients elsewhere)."""
+        if self.last_rast is None:
+            return None
+        return round(float((self.last_rast[..., 3] > 0).float().mean().item()), 4)
+
+    def profile_kernels(self, prof_steps, ms_per_step):
+        """Per-kernel hipEvent timing inside the library (one chunk per launch) -> (kernels, roofline, path_frac)."""
+        lib, _capi = self.lib, self._capi
+        lib.nvdr_profile_reset()
+        lib.nvdr_profile_enable(1)
+        for _ in range(prof_steps):
+            self.pos.grad = None; self.shared.grad = None
+            if self.full:
+                self.tex.grad = None
+            out, _ = self.render(self.pos)
+            torch.autograd.backward(out, self.G)
+        torch.cuda.synchronize()
+        prof = _capi.profile_read()
+        lib.nvdr_profile_enable(0)
+        lib.nvdr_profile_reset()
+        P_rank = self.N * self.RES * self.RES
+        alg, path_bytes = algorithmic_bytes(self.wl["graph"], P_rank, self.A, int(self.tri.shape[0]), self.N)
+        kernels = {}
+        for name, (total_ms, launches) in prof.items():
+            avg_ms = total_ms / max(launches, 1)
+            b = alg.get(name)
+            kernels[name] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches / prof_steps,
+                             "alg_bytes": b, "gbs": None if b is None else round(b / (avg_ms * 1e-3) / 1e9, 1)}
+        # Dominant kernel = the longest one (time per step), full stop.
+        dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
+        dk = kernels[dominant]
+        traffic = source = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")          # PMC-derived HBM bytes/launch, builder session
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(self.name, tj if self.name == "ch" else {})
+                if self.N == self.wl["per_gpu"]:
+                    traffic = ent.get(dominant)
+                    source = "profiles/traffic.json (%s): rocprofv3 PMC passes of a builder session, not measured in this run" % tj.get("_source", "builder session")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        sec = dk["avg_ms"] * 1e-3
+        roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["gbs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": None if dk["gbs"] is None else round(dk["gbs"] / HBM_PEAK_GBS, 4),
+                    "frac_is": "algorithmic bytes (SURVEY 8(d)) / time / peak",
+                    "traffic": traffic, "traffic_source": source if traffic else None,
+                    "traffic_ratio": None if not (traffic and dk["alg_bytes"]) else round(traffic / dk["alg_bytes"], 3),
+                    "hbm_frac_counter": None if not traffic else round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4),
+                    "kernel_avg_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes"]}
+        path_frac = round((path_bytes / (max(ms_per_step, 1e-9) * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)
+        return kernels, roofline, path_frac
+
+    def checker(self):
+        import oracle
+        from oracle import ref as oref
+        return (oref, "reference (oracle/_ref)") if oref.available() else (oracle, "oracle")
+
+    def parity(self):
+        """This very workload (its inputs, its resolution) against the reference itself, a bounded number of items."""
+        chk, chk_name = self.checker()
+        dr, sc, RES, dev = self.dr, self.scene, self.RES, self.dev
+        err = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())   # noqa: E731
+        mag = lambda a: float(np.abs(a).max())                                                            # noqa: E731
+        if not self.full:
+            ns = min(2, self.N)
+            ro, _ = chk.rasterize(sc["pos"][:ns], sc["tri"], (RES, RES))
+            Gs = self.G[:ns].cpu().numpy()
+            ga_o, gr_o, _ = chk.interpolate_grad(sc["attr"], ro, sc["tri"], Gs)
+            gp_o = chk.rasterize_grad(sc["pos"][:ns], sc["tri"], ro, gr_o)
+            pos_s = torch.from_numpy(sc["pos"][:ns]).to(dev).requires_grad_(True)
+            attr_s = torch.from_numpy(sc["attr"]).to(dev).requires_grad_(True)
+            r_s, _ = dr.rasterize(self.ctx, pos_s, self.tri, (RES, RES))
+            o_s, _ = dr.interpolate(attr_s, r_s, self.tri)
+            torch.autograd.backward(o_s, self.G[:ns])
+            r_h = r_s.detach().cpu().numpy()
+            return {"against": chk_name, "items": ns, "resolution": [RES, RES],
+                    "tri_id_mismatches": int((r_h[..., 3] != ro[..., 3]).sum()),
+                    "bary_max_abs_err": err(r_h[..., :3], ro[..., :3]),
+                    "g_attr_max_abs_err": err(attr_s.grad.cpu().numpy(), ga_o), "g_attr_max_abs": mag(ga_o),
+                    "g_pos_max_abs_err": err(pos_s.grad.cpu().numpy(), gp_o), "g_pos_max_abs": mag(gp_o)}
+        # four-op chain, one item at the config's own resolution and texture size
+        ns = 1
+        p_np, tri_np, uv_np = sc["pos"][:ns], sc["tri"], sc["uv"]
+        r, rdb = chk.rasterize(p_np, tri_np, (RES, RES))
+        uv_r, uvda_r = chk.interpolate(uv_np, r, tri_np, rdb, "all")
+        col_r = chk.texture(self.tex_np, uv_r, uvda_r, filter_mode="linear-mipmap-linear")
+        aa_r = chk.antialias(col_r, r, p_np, tri_np)
+        dy = self.G[:ns].cpu().numpy()
+        g_col, g_pos_aa = chk.antialias_grad(col_r, r, p_np, tri_np, dy)
+        g = chk.texture_grad(self.tex_np, uv_r, g_col, uvda_r, filter_mode="linear-mipmap-linear")
+        g_uvattr, g_rast, g_rdb = chk.interpolate_grad(uv_np, r, tri_np, g["uv"], rdb, g["uv_da"], "all")
+        g_pos = chk.rasterize_grad(p_np, tri_np, r, g_rast, g_rdb) + g_pos_aa
+        pos_s = torch.from_numpy(p_np).to(dev).requires_grad_(True)
+        uv_s = torch.from_numpy(uv_np).to(dev).requires_grad_(True)
+        tex_s = torch.from_numpy(self.tex_np).to(dev).requires_grad_(True)
+        rast, rast_db = dr.rasterize(self.ctx, pos_s, self.tri, (RES, RES))
+        uv, uv_da = dr.interpolate(uv_s, rast, self.tri, rast_db=rast_db, diff_attrs="all")
+        col = dr.texture(tex_s, uv, uv_da, filter_mode="linear-mipmap-linear")
+        aa = dr.antialias(col, rast, pos_s, self.tri, topology_hash=self.topo)
+        torch.autograd.backward(aa, self.G[:ns])
+        r_h = rast.detach().cpu().numpy()
+        return {"against": chk_name, "items": ns, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]),
+                "tri_id_mismatches": int((r_h[..., 3] != r[..., 3]).sum()),
+                "bary_max_abs_err": err(r_h[..., :3], r[..., :3]),
+                "col_max_abs_err": err(col.detach().cpu().numpy(), col_r),
+                "aa_max_abs_err": err(aa.detach().cpu().numpy(), aa_r),
+                "g_tex_max_abs_err": err(tex_s.grad.cpu().numpy(), g["tex"]), "g_tex_max_abs": mag(g["tex"]),
+                "g_uvattr_max_abs_err": err(uv_s.grad.cpu().numpy(), g_uvattr), "g_uvattr_max_abs": mag(g_uvattr),
+                "g_pos_max_abs_err": err(pos_s.grad.cpu().numpy(), g_pos), "g_pos_max_abs": mag(g_pos)}
+
+    def cpu_baselines(self, cpu_items):
+        """The CPU oracle (and the reference under its CPU shim) on this host's cores, bounded samples of this batch."""
+        import oracle
+        from oracle import ref as oref
+        sc, RES, N = self.scene, self.RES, self.N
+
+        def chain(mod, n, Gc):
+            pc, tc = sc["pos"][:n], sc["tri"]
+            if not self.full:
+                r_c, _ = mod.rasterize(pc, tc, (RES, RES))
+                mod.interpolate(sc["attr"], r_c, tc)
+                _ga, gr, _ = mod.interpolate_grad(sc["attr"], r_c, tc, Gc)
+                mod.rasterize_grad(pc, tc, r_c, gr)
+                return
+            r, rdb = mod.rasterize(pc, tc, (RES, RES))
+            uv_r, uvda_r = mod.interpolate(sc["uv"], r, tc, rdb, "all")
+            col_r = mod.texture(self.tex_np, uv_r, uvda_r, filter_mode="linear-mipmap-linear")
+            mod.antialias(col_r, r, pc, tc)
+            g_col, _gp = mod.antialias_grad(col_r, r, pc, tc, Gc)
+            g = mod.texture_grad(self.tex_np, uv_r, g_col, uvda_r, filter_mode="linear-mipmap-linear")
+            _ga, g_rast, g_rdb = mod.interpolate_grad(sc["uv"], r, tc, g["uv"], rdb, g["uv_da"], "all")
+            mod.rasterize_grad(pc, tc, r, g_rast, g_rdb)
+
+        nc = max(1, min(cpu_items, N))
+        Gc = self.G[:nc].cpu().numpy()
+        reps = 5 if not self.full else 3
+        times = []
+        for _rep in range(reps):
+            t1 = time.perf_counter()
+            chain(oracle, nc, Gc)
+            times.append(time.perf_counter() - t1)
+        tmed = sorted(times)[len(times) // 2]
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except Exception:  # noqa: BLE001
+            affinity = None
+        threads = oracle.num_threads()
+        cpu = {"value": round(nc * RES * RES / tmed / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+               "sample": f"{nc} of the {N} items of the same batch, fwd+bwd, median of {reps} (the reference has no CPU path; this is "
+                         f"the repo's C/OpenMP restatement, pinned to the reference by the tests). cores = the OpenMP team it ran "
+                         f"with, omp_get_max_threads() = {threads}: OpenMP sizes its default team from the CPUs this process may run "
+                         f"on (affinity mask: {affinity}), not from os.cpu_count() = {os.cpu_count()} logical CPUs of the host"}
+        cpu_ref = None
+        if oref.available():
+            nr = min(4 if not self.full else 1, N)
+            t1 = time.perf_counter()
+            chain(oref, nr, self.G[:nr].cpu().numpy())
+            tr = time.perf_counter() - t1
+            cpu_ref = {"value": round(nr * RES * RES / tr / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                       "sample": f"{nr} item(s) of the same batch, fwd+bwd, one run: the reference's own CUDA kernels and "
+                                 f"CudaRaster compiled for the host and executed by a fibre-based CUDA-on-CPU shim "
+                                 f"(oracle/refshim) -- an emulation on one thread, not a tuned CPU implementation"}
+        return cpu, cpu_ref
+
+
+def window_stats(host_s, evt_ms, steps):
+    per = sorted(h / steps * 1e3 for h in host_s)
+    med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+    ev = sorted(e / steps for e in evt_ms)
+    return med, {"windows": len(per), "steps_per_window": steps, "ms_per_step_median": round(med, 4),
+                 "ms_per_step_min": round(per[0], 4), "ms_per_step_max": round(per[-1], 4),
+                 "ms_per_step_windows": [round(h / steps * 1e3, 4) for h in host_s],
+                 "hip_event_ms_per_step_median": round(ev[len(ev) // 2], 4),
+                 "clock": "host perf_counter around barrier+synchronize brackets (max over ranks); hip_event_* = torch.cuda.Event pair "
+                          "on the launch stream around the same steps"}
+
+
+def extra_config(name, dev, steps, warmup, windows, with_cpu):
+    """One more BASELINE config measured in this process (single GPU): the block that goes under `configs`."""
+    wl = WORKLOADS[name]
+    N = wl["per_gpu"]
+    job = Job(name, N, N, 0, 0, 1, dev, False, wl["res"], False, 1, False)
+    host, evt = job.timed_windows(job.step, warmup, steps, windows)
+    ms, timing = window_stats(host, evt, steps)
+    kernels, roofline, path_frac = job.profile_kernels(max(3, min(steps, 5)), ms)
+    P = N * wl["res"] * wl["res"]
+    block = {"metric": wl["metric"], "value": round(P / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(ms, 4),
+             "steps": steps, "warmup": warmup, "timing": timing, "batch": N, "resolution": [wl["res"], wl["res"]],
+             "coverage": job.coverage(), "launch": "eager",
+             "roofline": roofline, "path_hbm_frac": path_frac, "kernels": kernels, "parity": job.parity()}
+    if with_cpu:
+        cpu, cpu_ref = job.cpu_baselines(4 if job.full else 16)
+        block["cpu_baseline"], block["cpu_reference"] = cpu, cpu_ref
+    del job
+    torch.cuda.empty_cache()
+    return block
+
+
+def c5_standin():
+    """BASELINE configs[4]: the reference's earth.py needs a release asset (earth.npz) that no checkout holds; the same op
+    graph and sizes (2048^2 reference render, 512^2 candidate, 2048^2 texture, Adam, 200 iterations) on a procedural globe."""
+    sys.path.insert(0, os.path.join(ROOT, "samples"))
+    import fit_texture_synth
+    fit_texture_synth.fit(iters=10, res=512, ref_res=2048, tex_size=2048)                       # warm-up: allocations, scratch
+    r = fit_texture_synth.fit(iters=200, res=512, ref_res=2048, tex_size=2048)
+    r["what"] = "samples/fit_texture_synth.py: all four ops fwd+bwd + Adam per iteration, eager launching; stands in for samples/torch/earth.py"
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5, help="timing windows of --steps steps each; the median window is reported")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="ch")
     ap.add_argument("--batch", type=int, default=None, help="items per GPU (overrides the workload's)")
     ap.add_argument("--res", type=int, default=None, help="resolution (overrides the workload's; dry runs use a small one)")
     ap.add_argument("--chunks", type=int, default=None,
                     help="N > 1: the rank's items are rendered in this many chunks so that a chunk's image all-gather "
-                         "overlaps the next chunk's kernels (default: chunks of >= 64 items, at most 4; 1 at N = 1)")
+                         "overlaps the next chunk's kernels (default: from the link / host arithmetic, see plan_chunks; 1 at N = 1)")
     ap.add_argument("--no-gather-images", action="store_true", help="N > 1: keep the output images sharded (no all-gather in the step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="default run: do not also measure BASELINE configs[1], [2], [4]")
     ap.add_argument("--cpu-items", type=int, default=64, help="items in the CPU-oracle sample")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into one hipGraph and time replays (single GPU only; the default, and the "
@@ -184,105 +581,33 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)     # RCCL over xGMI
 
     from nvdiffrast_amd import parallel
-    from nvdiffrast_amd.parallel import broadcast_shared, allreduce_shared_grads, gather_items_async, shard_range
+    from nvdiffrast_amd.parallel import shard_range
     parallel.force_collectives(args.force_collectives)
-    from nvdiffrast_amd.utils import m10k_batch
 
     wl = WORKLOADS[args.workload]
     RES = args.res or (32 if dry else wl["res"])
-    A = wl["attrs"]
-    full = wl["graph"] == "full"
     if wl["total"] is not None:                                   # strong scaling: a fixed batch split over the ranks
         total_items = wl["total"] if args.batch is None else args.batch * world
         first, N = shard_range(total_items, world, rank)
     else:
         N = args.batch or wl["per_gpu"]
         total_items, first = N * world, N * rank
-    # A chunk must carry enough pixels to cover the host's launch work for it (measured: 16-item chunks at 512^2 doubled the
-    # step time, 64-item chunks cost nothing); with one chunk the gather still overlaps the backward kernels.
-    chunks = args.chunks or (max(1, min(4, N // 64)) if distributed else 1)
-    chunks = max(1, min(chunks, N))
     gather = distributed and not args.no_gather_images
+    C_out = 3 if wl["graph"] == "full" else wl["attrs"]
+    item_bytes = RES * RES * C_out * 4
+    # chunk policy: from the bytes one link has to carry against the rank's predicted compute and the host's launch cost
+    # (plan_chunks); the per-item compute estimate is the single-GPU measurement of this tree, refined below
+    est_ms_per_item = (0.0080 if wl["graph"] == "ri" else 0.105) * (RES * RES) / (wl["res"] * wl["res"])
+    n_max = -(-total_items // world)
+    chunks, chunk_plan = plan_chunks(n_max, item_bytes, n_max * est_ms_per_item, (world - 1) if gather else 0)
+    if args.chunks:
+        chunks = args.chunks
+    if not gather:
+        chunks = args.chunks or 1
 
-    # Per-item poses differ across ranks; geometry every item shares (tri, attr/uv, texture) comes from rank 0 over
-    # RCCL, as it would in a data-parallel job.
-    if dry:
-        scene = m10k_batch(N, seed=20240, attrs=A, nx=8, ny=4, pose_seed=20240 + 1000 * rank)
-    else:
-        scene = m10k_batch(N, seed=20240, attrs=A, pose_seed=20240 + 1000 * rank)
-    pos = torch.from_numpy(scene["pos"]).to(dev).requires_grad_(True)
-    tri = torch.from_numpy(scene["tri"]).to(dev)
-    shared = torch.from_numpy(scene["uv"] if full else scene["attr"]).to(dev)
-    C_out = 3 if full else A
-    tex = None
-    if full:
-        tex_res = 2048 if not dry else 32
-        tex = torch.from_numpy(np.random.default_rng(5).uniform(size=(1, tex_res, tex_res, 3)).astype(np.float32)).to(dev)
-    if distributed:
-        broadcast_shared([tri, shared] + ([tex] if full else []), src=0)
-    shared.requires_grad_(True)
-    if full:
-        tex.requires_grad_(True)
-    G = torch.from_numpy(np.random.default_rng(77 + rank).normal(size=(N, RES, RES, C_out)).astype(np.float32)).to(dev)
+    job = Job(args.workload, N, total_items, first, rank, world, dev, dry, RES, distributed, chunks, gather)
 
-    if dry:
-        kernels_impl = DryKernels(dev)
-        dr = ctx = topo = None
-    else:
-        import nvdiffrast_amd.torch as dr
-        from nvdiffrast_amd import _capi
-        lib = _capi.load()
-        ctx = dr.RasterizeCudaContext(device=dev)
-        topo = dr.antialias_construct_topology_hash(tri) if full else None
-
-    bounds = [(N * c // chunks, N * (c + 1) // chunks) for c in range(chunks)]
-    mode = {"gather": gather}                                     # switched off for the second, gather-free timing below
-    gathered = [None] * chunks                                    # receive buffers, reused every step
-
-    def render(p):
-        """Forward of the op graph for the items `p` [n,V,4] -> output image [n,H,W,C]."""
-        if dry:
-            return kernels_impl.forward(p, shared, RES, C_out), None
-        rast, rast_db = dr.rasterize(ctx, p, tri, (RES, RES))
-        if not full:
-            out, _ = dr.interpolate(shared, rast, tri)
-            return out, rast
-        uv, uv_da = dr.interpolate(shared, rast, tri, rast_db=rast_db, diff_attrs="all")
-        col = dr.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear")
-        return dr.antialias(col, rast, p, tri, topology_hash=topo), rast
-
-    def step():
-        pos.grad = None
-        shared.grad = None
-        if full:
-            tex.grad = None
-        pending = []
-        last = None
-        for c, (a, b) in enumerate(bounds):
-            p = pos if chunks == 1 else pos[a:b]
-            out, rast = render(p)
-            if mode["gather"]:
-                # the collective runs on RCCL's own stream, ordered after this chunk's kernels; the next chunk's
-                # kernels are issued right away and overlap it
-                work, gathered[c] = gather_items_async(out.detach(), out=gathered[c])
-                pending.append(work)
-            torch.autograd.backward(out, G if chunks == 1 else G[a:b])
-            last = (rast, out)
-        if distributed:
-            allreduce_shared_grads([shared] + ([tex] if full else []))
-        for w in pending:
-            w.wait()
-        return last
-
-    def fence():
-        if not dry:
-            torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        if not dry:
-            torch.cuda.synchronize()
-
-    run = step
+    run = job.step
     if args.graph:
         # No op of the path synchronises the host or allocates at the C-ABI level, so the whole step captures.
         assert not distributed and not dry, "--graph is a single-GPU measurement"
@@ -290,29 +615,15 @@ def main():
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                step()
+                job.step()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            step()
+            job.step()
         run = graph.replay
-    def timed(warmup, steps):
-        """`steps` steps bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
-        for _ in range(warmup):
-            run()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            run()
-        fence()
-        el = time.perf_counter() - t0
-        if distributed:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return el
 
-    elapsed = timed(args.warmup, args.steps)
+    host, evt = job.timed_windows(run, args.warmup, args.steps, max(1, args.windows))
+    ms_per_step, timing = window_stats(host, evt, args.steps)
     ranks_seen = world
     if distributed:
         ones = torch.ones(1, dtype=torch.float64, device=dev)
@@ -322,143 +633,79 @@ def main():
     # The image all-gather is pure xGMI traffic whose size does not depend on how fast the kernels are: report the
     # same job without it next to `value`, and the link arithmetic, so that the two effects can be told apart.
     collective = None
-    if gather:
-        mode["gather"] = False
-        elapsed_ng = timed(min(args.warmup, 2), args.steps)
-        mode["gather"] = True
-        img_bytes = N * RES * RES * C_out * 4
+    if distributed:
+        ms_ng = ms_per_step
+        if gather:
+            job.gather_on = False
+            host_ng, evt_ng = job.timed_windows(run, min(args.warmup, 2), args.steps, max(1, min(args.windows, 3)))
+            job.gather_on = True
+            ms_ng, _ = window_stats(host_ng, evt_ng, args.steps)
+        img_bytes = N * item_bytes
         links = world - 1                                         # fully connected xGMI: one link per peer (0: a forced group of one)
         collective = {
-            "image_bytes_sent_per_rank_per_step": img_bytes * links, "image_bytes_received_per_rank_per_step": img_bytes * links,
+            "image_gather_in_step": bool(gather),
+            "image_bytes_sent_per_rank_per_step": img_bytes * links if gather else 0,
+            "image_bytes_received_per_rank_per_step": img_bytes * links if gather else 0,
             "xgmi_links_per_gpu_used": links, "xgmi_link_gbs": XGMI_LINK_GBS,
             # every link carries one rank's images, all links in parallel: the floor does not shrink with more GPUs
             "xgmi_floor_ms": round(img_bytes / (XGMI_LINK_GBS * 1e9) * 1e3, 4) if links else None,
-            "ms_per_step_without_image_gather": round(elapsed_ng / args.steps * 1e3, 4),
-            "value_without_image_gather": round(total_items * RES * RES / (elapsed_ng / args.steps) / 1e6, 1),
+            "ms_per_step_without_image_gather": round(ms_ng, 4),
+            "value_without_image_gather": round(total_items * RES * RES / (ms_ng * 1e-3) / 1e6, 1),
+            "chunks": job.chunks, "chunk_plan": chunk_plan,
+            # the curve the link arithmetic predicts, from THIS run's compute time per item (gather-free step / items)
+            "predicted_scaling": predicted_scaling(ms_ng / max(N, 1), wl["scaling"], wl["per_gpu"] or N, wl["total"] or total_items, item_bytes),
         }
 
-    P_rank = N * RES * RES
     P_total = total_items * RES * RES
-    ms_per_step = elapsed / args.steps * 1e3
-    value = P_total / (elapsed / args.steps) / 1e6                # whole-job Mpixels/s
+    value = P_total / (ms_per_step * 1e-3) / 1e6                  # whole-job Mpixels/s
 
     result = None
     if rank == 0:
-        kernels = roofline = parity = cpu = cpu_ref = None
+        kernels = roofline = parity = cpu = cpu_ref = configs = None
         path_frac = None
         if not dry:
-            # ---- per-kernel timing (hipEvents on the launch stream, inside the library), one chunk per launch ----
-            lib.nvdr_profile_reset()
-            lib.nvdr_profile_enable(1)
-            prof_steps = max(3, min(args.steps, 10))
-            for _ in range(prof_steps):
-                pos.grad = None; shared.grad = None
-                if full:
-                    tex.grad = None
-                out, _ = render(pos)
-                torch.autograd.backward(out, G)
-            torch.cuda.synchronize()
-            prof = _capi.profile_read()
-            lib.nvdr_profile_enable(0)
-            lib.nvdr_profile_reset()
-            alg, path_bytes = algorithmic_bytes(wl["graph"], P_rank, A, int(tri.shape[0]), N)
-            kernels = {}
-            for name, (total_ms, launches) in prof.items():
-                avg_ms = total_ms / max(launches, 1)
-                b = alg.get(name)
-                kernels[name] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches / prof_steps,
-                                 "alg_bytes": b, "gbs": None if b is None else round(b / (avg_ms * 1e-3) / 1e9, 1)}
-            # Dominant kernel = the longest one (time per step), full stop.
-            dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
-            dk = kernels[dominant]
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes/launch (CH), if collected
-            if args.workload == "ch" and N == 64 and os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dominant)
-                except Exception:  # noqa: BLE001
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["gbs"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": None if dk["gbs"] is None else round(dk["gbs"] / HBM_PEAK_GBS, 4),
-                        "traffic": traffic,
-                        "traffic_ratio": None if not (traffic and dk["alg_bytes"]) else round(traffic / dk["alg_bytes"], 3),
-                        "kernel_avg_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes"]}
-            step_ms_1gpu = sum(kernels[k]["avg_ms"] * kernels[k]["launches_per_step"] for k in kernels)
-            path_frac = round((path_bytes / (max(ms_per_step, 1e-9) * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)
-
-            # ---- parity of this workload against the reference itself (oracle/_ref) or the oracle ----------------
-            if world == 1 and not full:
-                import oracle
-                from oracle import ref as oref
-                chk, chk_name = (oref, "reference (oracle/_ref)") if oref.available() else (oracle, "oracle")
-                ns = 2
-                ro, _ = chk.rasterize(scene["pos"][:ns], scene["tri"], (RES, RES))
-                Gs = G[:ns].cpu().numpy()
-                ga_o, gr_o, _ = chk.interpolate_grad(scene["attr"], ro, scene["tri"], Gs)
-                gp_o = chk.rasterize_grad(scene["pos"][:ns], scene["tri"], ro, gr_o)
-                pos_s = torch.from_numpy(scene["pos"][:ns]).to(dev).requires_grad_(True)
-                attr_s = torch.from_numpy(scene["attr"]).to(dev).requires_grad_(True)
-                r_s, _ = dr.rasterize(ctx, pos_s, tri, (RES, RES))
-                o_s, _ = dr.interpolate(attr_s, r_s, tri)
-                torch.autograd.backward(o_s, G[:ns])
-                parity = {
-                    "against": chk_name, "items": ns,
-                    "tri_id_mismatches": int((r_s[..., 3].detach().cpu().numpy() != ro[..., 3]).sum()),
-                    "bary_max_abs_err": float(np.abs(r_s[..., :3].detach().cpu().numpy() - ro[..., :3]).max()),
-                    "g_attr_max_abs_err": float(np.abs(attr_s.grad.cpu().numpy() - ga_o).max()),
-                    "g_attr_max_abs": float(np.abs(ga_o).max()),
-                    "g_pos_max_abs_err": float(np.abs(pos_s.grad.cpu().numpy() - gp_o).max()),
-                    "g_pos_max_abs": float(np.abs(gp_o).max()),
-                }
-
-                # ---- CPU baselines on this host's cores, bounded samples ---------------------------------------
+            kernels, roofline, path_frac = job.profile_kernels(max(3, min(args.steps, 10)), ms_per_step)
+            if world == 1:
+                parity = job.parity()
                 if not args.no_cpu_baseline:
-                    def chain(mod, pc, tc, ac, Gc):
-                        r_c, _ = mod.rasterize(pc, tc, (RES, RES))
-                        mod.interpolate(ac, r_c, tc)
-                        _ga, gr, _ = mod.interpolate_grad(ac, r_c, tc, Gc)
-                        mod.rasterize_grad(pc, tc, r_c, gr)
-
-                    nc = max(1, min(args.cpu_items, N))
-                    Gc = G[:nc].cpu().numpy()
-                    times = []
-                    for _rep in range(5):
-                        t1 = time.perf_counter()
-                        chain(oracle, scene["pos"][:nc], scene["tri"], scene["attr"], Gc)
-                        times.append(time.perf_counter() - t1)
-                    tmed = sorted(times)[2]
-                    cpu = {"value": round(nc * RES * RES / tmed / 1e6, 2), "unit": "Mpixels/s", "cores": oracle.num_threads(),
-                           "kind": "port",
-                           "sample": f"{nc} of the {N} items of the same batch, fwd+bwd, median of 5 (the reference has no CPU "
-                                     f"path; this is the repo's C/OpenMP restatement, pinned to the reference by the tests), "
-                                     f"host cpu_count={os.cpu_count()}"}
-                    if oref.available():
-                        nr = min(4, N)
-                        t1 = time.perf_counter()
-                        chain(oref, scene["pos"][:nr], scene["tri"], scene["attr"], G[:nr].cpu().numpy())
-                        tr = time.perf_counter() - t1
-                        cpu_ref = {"value": round(nr * RES * RES / tr / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
-                                   "sample": f"{nr} items of the same batch, fwd+bwd, one run: the reference's own CUDA kernels and "
-                                             f"CudaRaster compiled for the host and executed by a fibre-based CUDA-on-CPU shim "
-                                             f"(oracle/refshim) -- an emulation on one thread, not a tuned CPU implementation"}
-
+                    cpu, cpu_ref = job.cpu_baselines(args.cpu_items if not job.full else min(args.cpu_items, 4))
+        coverage = None if dry else job.coverage()
+        full = job.full
         cfg = {"workload": "%s: random-pose 10k-triangle lattice mesh (T=%d, V=%d), %d items on this GPU of %d in total @%dx%d, %s, "
                            "upstream grad fed to backward directly"
-                           % (args.workload.upper(), int(tri.shape[0]), int(pos.shape[1]), N, total_items, RES, RES,
+                           % (args.workload.upper(), int(job.tri.shape[0]), int(job.pos.shape[1]), N, total_items, RES, RES,
                               "rasterize+interpolate(uv,da)+texture(2048^2 trilinear)+antialias fwd+bwd" if full
-                              else "A=%d attrs, rasterize+interpolate fwd+bwd" % A),
-               "batch_per_gpu": N, "total_items": total_items, "resolution": [RES, RES], "triangles": int(tri.shape[0]),
+                              else "A=%d attrs, rasterize+interpolate fwd+bwd" % job.A),
+               "batch_per_gpu": N, "total_items": total_items, "resolution": [RES, RES], "triangles": int(job.tri.shape[0]),
+               "coverage": coverage,
                "parallelism": "dp%d (items sharded; per step: %sall-reduce of the shared-input gradients)"
-                              % (world, ("all-gather of the output images in %d chunks overlapped with rendering, " % chunks) if gather else ""),
-               "chunks": chunks, "gather_images": bool(gather),
+                              % (world, ("all-gather of the output images in %d chunks overlapped with rendering, " % job.chunks) if gather else ""),
+               "chunks": job.chunks, "gather_images": bool(gather),
                "launch": "hipGraph replay" if args.graph else "eager"}
+        # ---- the other BASELINE configs, same process, single GPU, default run only ------------------------------------
+        if (not dry and world == 1 and not distributed and args.workload == "ch" and args.batch is None and args.res is None
+                and not args.graph and not args.no_extra_configs):
+            del job
+            torch.cuda.empty_cache()
+            configs = {}
+            for name, st in (("c2", 20), ("c3", 6)):
+                try:
+                    configs[name] = extra_config(name, dev, st, 3, 5, with_cpu=(name == "c3" and not args.no_cpu_baseline))
+                except Exception as e:  # noqa: BLE001
+                    configs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                configs["c5_standin"] = c5_standin()
+            except Exception as e:  # noqa: BLE001
+                configs["c5_standin"] = {"error": "%s: %s" % (type(e).__name__, e)}
         result = {
             "metric": wl["metric"],
             "value": round(value, 1), "unit": "Mpixels/s",
             "n_gpus": world, "rccl_ranks": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": wl["scaling"],
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_min": timing["ms_per_step_min"], "ms_per_step_max": timing["ms_per_step_max"],
+            "higher_is_better": True, "scaling": wl["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": cfg,
+            "timing": timing,
             "roofline": roofline,
             "path_hbm_frac": path_frac,
             "kernels": kernels,
@@ -466,13 +713,15 @@ def main():
             "cpu_reference": cpu_ref,
             "parity": parity,
             "collective": collective,
+            "configs": configs,
         }
         if dry:
             result["dry_run"] = True
             result["backend"] = "gloo" if distributed else "none"
             if gather:
-                g0 = gathered[0]
+                g0 = job.gathered[0]
                 result["gathered_rows_chunk0"] = int(g0.shape[0])
+                result["gathered_rows_total"] = int(sum(g.shape[0] for g in job.gathered))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

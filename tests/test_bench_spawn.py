@@ -58,7 +58,39 @@ def test_collectives_can_be_forced_on_a_single_rank():
     assert j["config"]["gather_images"] is True and j["config"]["chunks"] == 2 and j["collective"] is not None
 
 
-def test_default_chunking_keeps_chunks_large():
-    """Chunks below ~64 items leave the GPU waiting for the host (measured on the MI355X): the default never makes them."""
-    assert _run("--gpus", "2", "--batch", "4")["config"]["chunks"] == 1
-    assert _run("--gpus", "2", "--workload", "c4")["config"]["chunks"] == 2          # 128 items per rank
+def test_chunk_policy_follows_the_link_arithmetic():
+    """the chunk count comes from the bytes one link carries against the rank's compute and the host's
+    launch cost, not from items // 64 (which gave C4 at N = 8 one chunk: nothing overlapped the forward)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    item = 512 * 512 * 4 * 4
+    # C4 at N = 8: 32 items per GPU, 0.26 ms of kernels against 0.88 ms of gather: start the gather early (2 chunks), but
+    # never so many chunks that the host's launch work exceeds what the earlier start gains
+    c, plan = bench.plan_chunks(32, item, 32 * 0.008, 7)
+    assert c == 2 and abs(plan["gather_floor_ms"] - 0.877) < 0.01
+    assert bench.plan_chunks(64, item, 64 * 0.008, 7)[0] == 2                 # weak-scaled headline: gather-bound as well
+    assert bench.plan_chunks(64, item, 2.0, 7)[0] >= 3                        # kernels about as long as the gather: overlap pays, more chunks
+    assert bench.plan_chunks(64, item, 64 * 0.2, 7)[0] == 1                   # kernels far longer than the gather: it hides behind the backward pass
+    assert bench.plan_chunks(4, 32 * 32 * 16, 0.001, 1)[0] == 1               # tiny dry-run items: the host bounds everything
+    assert bench.plan_chunks(64, item, 0.5, 0) == (1, None)                   # nobody to send to
+    ps = bench.predicted_scaling(0.008, "strong", None, 256, item)
+    assert ps["with_image_gather"]["8"] < 3.0 < 6.0 < ps["without_image_gather"]["8"] <= 8.0
+    pw = bench.predicted_scaling(0.008, "weak", 64, None, item)
+    assert pw["with_image_gather"]["8"] < 3.0 and pw["without_image_gather"]["8"] > 7.0
+
+
+def test_default_chunking_in_a_spawned_job():
+    assert _run("--gpus", "2", "--batch", "4")["config"]["chunks"] == 1               # dry-run items are tiny: one chunk
+    j = _run("--gpus", "2", "--workload", "c4")
+    assert j["collective"]["chunk_plan"]["predicted_step_ms_by_chunks"] and j["collective"]["predicted_scaling"]["with_image_gather"]["8"] > 0
+
+
+def test_eight_ranks_c4():
+    """BASELINE configs[3] at its own world size (gloo stand-in): 256 items -> 32 per rank, every rank's chunks gathered,
+    all eight ranks inside the timed region, timing windows reported."""
+    j = _run("--gpus", "8", "--workload", "c4", "--windows", "2")
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["scaling"] == "strong"
+    assert j["config"]["total_items"] == 256 and j["config"]["batch_per_gpu"] == 32 and j["config"]["gather_images"] is True
+    assert j["gathered_rows_total"] == 256                                            # 8 ranks x 32 items arrived on rank 0
+    assert j["timing"]["windows"] == 2 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
+    assert j["collective"]["xgmi_links_per_gpu_used"] == 7

@@ -36,6 +36,31 @@ def test_default_line_contract():
     assert j["parity"]["tri_id_mismatches"] == 0
     assert j["parity"]["g_pos_max_abs_err"] <= 1e-5 * max(1.0, j["parity"]["g_pos_max_abs"])
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
+    assert j["timing"]["windows"] == 5 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
+    assert 0.0 < j["config"]["coverage"] < 1.0
+    assert j["configs"] is None                                           # a non-default batch: the headline only
+
+
+def test_default_run_carries_the_other_baseline_configs():
+    """the run the driver records (no workload flags) also measures BASELINE configs[1], [2] and the [4]
+    stand-in in the same process, each with per-kernel times, a roofline and a parity block of THAT workload at its full
+    size -- against the reference itself (oracle/_ref travels with the tree)."""
+    j = _bench("--no-cpu-baseline")
+    assert j["config"]["batch_per_gpu"] == 64 and j["parity"]["tri_id_mismatches"] == 0
+    cf = j["configs"]
+    assert set(cf) == {"c2", "c3", "c5_standin"}
+    for name in ("c2", "c3"):
+        c = cf[name]
+        assert "error" not in c, c
+        assert c["ms_per_step"] > 0 and c["roofline"]["kernel"] in c["kernels"] and 0 < c["roofline"]["frac"] < 1
+        assert c["parity"]["tri_id_mismatches"] == 0 and c["parity"]["bary_max_abs_err"] <= 1e-5
+        assert c["parity"]["g_pos_max_abs_err"] <= 2e-5 * max(1.0, c["parity"]["g_pos_max_abs"])
+    p3 = cf["c3"]["parity"]
+    assert p3["resolution"] == [1024, 1024] and p3["texture"] == [2048, 2048]
+    assert p3["col_max_abs_err"] <= 1.5e-5 and p3["aa_max_abs_err"] <= 1.5e-5
+    assert p3["g_tex_max_abs_err"] <= 1e-5 * max(1.0, p3["g_tex_max_abs"])
+    assert cf["c2"]["batch"] == 16 and cf["c3"]["batch"] == 32
+    assert cf["c5_standin"]["iters_per_s"] > 0 and cf["c5_standin"]["loss_last"] < cf["c5_standin"]["loss_first"]
 
 
 @pytest.mark.parametrize("workload", ["ch", "c4"])
