@@ -50,6 +50,30 @@ def oracle(raw_oracle):
     return po
 
 
+# ---- the parity bars, stated once (DESIGN.md section 2 quotes this block) ------------------------------------------------
+# integers (triangle ids, U32 depths): identical.
+# forward floats of ONE op on identical inputs (barycentrics, z/w, attributes, texture samples, blended colours): 1e-5 abs.
+# gradients of ONE op on identical inputs: 1e-5 * max(1, |g|_inf) -- every gradient on this path is a SUM of per-pixel
+#   terms (the reference's with f32 atomics in launch order, the oracle's in f64, this library's in fixed point), and an f32
+#   sum cannot be defined better than the ulp of its largest term: position gradients of the benchmark scene reach 1.8e4,
+#   where 1e-5 abs would be a hundredth of an ulp.
+# a CHAIN of k ops compared end to end: every op is handed its predecessor's output, which is defined only to that
+#   op's bar, and passes the difference on through its own Jacobian: k * the single-op gradient bar (CHAIN_OPS = 4 for
+#   rasterize -> interpolate -> texture -> antialias), and CHAIN_VALUE_TOL = 2e-5 abs for the colours at the end of the
+#   forward chain: an interpolated uv is defined to about 1 ulp (6e-8) by the order of three f32 products, and a texture
+#   turns a uv difference into a colour difference of (texels per unit uv at the sampled level) x (difference of
+#   neighbouring texels) -- for a random 2048^2 texture sampled at about one texel per pixel that is up to
+#   6e-8 x 1024 x 1 = 6e-5 in the worst case and 9e-6 at the worst pixel measured.
+ATOL = 1e-5
+CHAIN_OPS = 4
+CHAIN_VALUE_TOL = 2e-5
+
+
+def grad_tol(g, ops=1):
+    import numpy as np
+    return ops * ATOL * max(1.0, float(np.abs(g).max()))
+
+
 _MARGINS = {}
 
 

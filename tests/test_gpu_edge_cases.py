@@ -170,3 +170,70 @@ def test_context_reuse_across_layouts_and_scenes(dr, oracle):
         r = r.cpu().numpy()
         assert (r[..., 3] != want[key][..., 3]).sum() == 0, f"call {i}"
         assert np.abs(r[..., :3] - want[key][..., :3]).max() <= 1e-5, f"call {i}"
+
+
+def _encode_ids(ids):
+    """triidx_to_float (common.h:192-193): exact floats up to 2^24, bit-offset floats above."""
+    ids = np.asarray(ids, np.int64)
+    small = ids.astype(np.float32)
+    big = (np.int64(0x4A800000) + ids).astype(np.uint32).view(np.float32)
+    return np.where(ids <= 0x01000000, small, big).astype(np.float32)
+
+
+def test_triangle_ids_above_2_pow_24_survive_the_float_channel(dr, raw_oracle):
+    """common.h:186-193: a triangle id above 2^24 cannot be stored in an f32 as a number, so the id channel carries
+    it as a bit-offset float.  A mesh of 2^24 + 16 triangles whose LAST 16 are visible: interpolate (fwd + grad),
+    rasterize_grad and antialias (fwd + grad) must decode the ids exactly as the oracle does.
+    The rast tensor is made from a rasterization of the 16 visible triangles with the id channel re-based."""
+    from nvdiffrast_amd.torch import _plugin
+    oracle = raw_oracle                                     # the reference under its CPU shim would run 2^24 fibres for the hash
+    T = (1 << 24) + 16
+    small = m10k_batch(1, seed=5, nx=4, ny=2)               # 3 x 5 lattice: 16 triangles, 15 vertices
+    assert small["tri"].shape[0] == 16
+    res = (96, 96)
+    ro, rdbo = oracle.rasterize(small["pos"], small["tri"], res)
+    ids = ro[..., 3].astype(np.int64)
+    big_ids = np.where(ids > 0, ids + (T - 16), 0)
+    assert big_ids.max() > (1 << 24) and (big_ids > (1 << 24)).sum() > 500
+    rast = ro.copy()
+    rast[..., 3] = _encode_ids(big_ids)
+    tri = np.zeros((T, 3), np.int32)
+    tri[T - 16:] = small["tri"]
+    rng = np.random.default_rng(3)
+    A = 4
+    attr = rng.uniform(size=(1, small["pos"].shape[1], A)).astype(np.float32)
+    G = rng.normal(size=(1,) + res + (A,)).astype(np.float32)
+    t_tri, t_rast = _t(tri), _t(rast)
+
+    # interpolate forward + backward
+    t_attr = _t(attr).requires_grad_(True)
+    t_rast_g = _t(rast).requires_grad_(True)
+    out, _ = dr.interpolate(t_attr, t_rast_g, t_tri)
+    out.backward(_t(G))
+    oo, _ = oracle.interpolate(attr, rast, tri)
+    ga, gr, _ = oracle.interpolate_grad(attr, rast, tri, G)
+    assert np.abs(oo).max() > 0.1                                                     # the big ids really resolve to triangles
+    assert np.abs(out.detach().cpu().numpy() - oo).max() <= 1e-5
+    assert np.abs(t_attr.grad.cpu().numpy() - ga).max() <= 1e-5 * max(1.0, np.abs(ga).max())
+    assert np.abs(t_rast_g.grad.cpu().numpy() - gr).max() <= 1e-5 * max(1.0, np.abs(gr).max())
+
+    # rasterize backward (with the pixel-differential gradients)
+    dy = rng.normal(size=rast.shape).astype(np.float32)
+    ddb = rng.normal(size=rast.shape).astype(np.float32)
+    gp = _plugin.rasterize_grad_db(_t(small["pos"]), t_tri, t_rast, _t(dy), _t(ddb)).cpu().numpy()
+    gpo = oracle.rasterize_grad(small["pos"], tri, rast, dy, ddb)
+    assert np.abs(gpo).max() > 0 and np.abs(gp - gpo).max() <= 1e-5 * max(1.0, np.abs(gpo).max())
+
+    # antialias forward + backward (topology hash over all 2^24 + 16 triangles)
+    col = rng.uniform(size=(1,) + res + (3,)).astype(np.float32)
+    t_col = _t(col).requires_grad_(True)
+    t_pos = _t(small["pos"]).requires_grad_(True)
+    aa = dr.antialias(t_col, t_rast, t_pos, t_tri)
+    dya = rng.normal(size=col.shape).astype(np.float32)
+    aa.backward(_t(dya))
+    aao = oracle.antialias(col, rast, small["pos"], tri)
+    gc, gpa = oracle.antialias_grad(col, rast, small["pos"], tri, dya)
+    assert np.abs(aao - col).max() > 1e-3                                             # silhouettes were found and blended
+    assert np.abs(aa.detach().cpu().numpy() - aao).max() <= 1e-5
+    assert np.abs(t_col.grad.cpu().numpy() - gc).max() <= 1e-5 * max(1.0, np.abs(gc).max())
+    assert np.abs(t_pos.grad.cpu().numpy() - gpa).max() <= 1e-5 * max(1.0, np.abs(gpa).max())

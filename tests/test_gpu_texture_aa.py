@@ -1,12 +1,12 @@
 """GPU parity: HIP texture / antialias (through the C ABI) vs the CPU oracle, plus the whole
 four-op chain (BASELINE config 3's op graph at a size the oracle finishes in seconds).
 
-Bars: sampled values within 1e-5 abs; gradients within 1e-5 * max(1, |g|_inf).  A pixel whose
-footprint sits exactly on a mip-level boundary may pick the neighbouring level on one side
-(1-ulp difference in log2): such pixels are allowed at a rate below 1e-3 and are still continuous."""
+Bars (stated once in tests/conftest.py): sampled values within 1e-5 abs; gradients within 1e-5 * max(1, |g|_inf); a
+chain of four ops compared end to end k = 4 times that, colours at the end of the chain 2e-5.  No element is exempted."""
 import numpy as np
 import pytest
 import torch
+from conftest import CHAIN_OPS, CHAIN_VALUE_TOL, grad_tol, within
 
 from nvdiffrast_amd.utils import m10k_batch
 
@@ -254,7 +254,7 @@ def test_antialias_forward_backward(dr, oracle):
     out2 = dr.antialias(_t(color), _t(ro), t_pos2, tri, topology_hash=h, pos_gradient_boost=3.0)
     out2.backward(_t(dy))
     _close(out2.detach().cpu().numpy(), oo, ATOL)
-    _close(t_pos2.grad.cpu().numpy(), 3.0 * gp, _tol(gp) * 12)
+    within("antialias boosted g_pos", t_pos2.grad.cpu().numpy(), 3.0 * gp, grad_tol(3.0 * gp))     # the bar of the boosted gradient itself
 
 
 def test_antialias_range_mode_and_split_vertices(dr, oracle):
@@ -303,16 +303,16 @@ def test_full_chain_config3(dr, oracle):
     outo = oracle.antialias(colo, ro, b["pos"], b["tri"])
     assert (rast[..., 3].detach().cpu().numpy() != ro[..., 3]).sum() == 0
     _close(uv_da.detach().cpu().numpy(), uvdao, _tol(uvdao))
-    _close(col.detach().cpu().numpy(), colo, 2e-5)
-    _close(out.detach().cpu().numpy(), outo, 2e-5)
+    within("chain vs oracle: col", col.detach().cpu().numpy(), colo, CHAIN_VALUE_TOL)       # end of a forward chain (conftest.py)
+    within("chain vs oracle: aa", out.detach().cpu().numpy(), outo, CHAIN_VALUE_TOL)
 
     g_col, g_pos_aa = oracle.antialias_grad(colo, ro, b["pos"], b["tri"], G)
     tg = oracle.texture_grad(tex, uvo, g_col, uvdao, filter_mode="linear-mipmap-linear")
     g_uvattr, g_rast, g_rdb = oracle.interpolate_grad(b["uv"], ro, b["tri"], tg["uv"], rast_db=rdbo, dda=tg["uv_da"], diff_attrs="all")
     g_pos = oracle.rasterize_grad(b["pos"], b["tri"], ro, g_rast, ddb=g_rdb) + g_pos_aa
     _close(t_tex.grad.cpu().numpy(), tg["tex"], _tol(tg["tex"]))
-    _close(uvattr.grad.cpu().numpy(), g_uvattr, _tol(g_uvattr) * 8)
-    _close(pos.grad.cpu().numpy(), g_pos, _tol(g_pos) * 8)
+    within("chain vs oracle: g_uvattr", uvattr.grad.cpu().numpy(), g_uvattr, grad_tol(g_uvattr, CHAIN_OPS))   # four ops end to end
+    within("chain vs oracle: g_pos", pos.grad.cpu().numpy(), g_pos, grad_tol(g_pos, CHAIN_OPS))
 
 
 @pytest.mark.parametrize("bm", ["wrap", "clamp", "zero"])
