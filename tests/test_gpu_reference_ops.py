@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 import pytest
-from conftest import within
+from conftest import ATOL, CHAIN_OPS, CHAIN_VALUE_TOL, grad_tol, within
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -79,3 +79,34 @@ def test_the_references_own_ops_py_runs_on_the_plugin(dr, fx):
     out, _ = ref_dr.interpolate(col, rast, tri)
     img = np.clip(np.rint(out.cpu().numpy()[0, ::-1, :, :] * 255), 0, 255).astype(np.uint8)
     assert (img != np.array(Image.open(os.path.join(HERE, "golden", "tri.png")))).sum() == 0
+
+
+def test_replay_of_the_reference_ops_transcript(dr):
+    """The drop-in claim without the reference checkout: every call the reference's OWN ops.py makes into
+    `_nvdiffrast_c` over the fixture scenes and the remaining entry points -- 47 calls, all 19 functions and 3 classes of
+    torch_bindings.cpp:43-71, recorded in the build container by tests/golden/make_ops_transcript.py with the reference's
+    results -- is issued against nvdiffrast_amd.torch._plugin with the recorded argument structure.  Arity, shapes and
+    dtypes must be the recorded ones; values within the bars of tests/conftest.py (single-op bars where a call's inputs are
+    the recorded literals, chain bars where they are this replay's own earlier results)."""
+    from nvdiffrast_amd.torch import _plugin
+    from replay_ops import replay
+    seen = set()
+
+    def on_tensor(call, idx, got, want, chained):
+        fn = call["fn"]
+        seen.add(fn)
+        name = "transcript: %s[%d]" % (fn, idx)
+        if fn == "rasterize_fwd_cuda" and idx == 0:
+            assert (got[..., 3] != want[..., 3]).sum() == 0, "triangle ids differ from the reference's"
+            within(name, got[..., :3], want[..., :3], ATOL)
+        elif want.dtype.kind in "iu":
+            assert np.array_equal(got, want), name
+        elif "grad" in fn or (fn == "rasterize_fwd_cuda" and idx == 1) or (fn == "interpolate_fwd_da" and idx == 1):
+            within(name, got, want, grad_tol(want, CHAIN_OPS if chained else 1))
+        else:
+            within(name, got, want, CHAIN_VALUE_TOL if chained else ATOL)
+
+    doc, _ = replay(_plugin, "cuda", on_tensor)
+    assert len(doc["calls"]) >= 47 and len({c["fn"] for c in doc["calls"]}) >= 20
+    assert {"rasterize_fwd_cuda", "rasterize_grad", "rasterize_grad_db", "interpolate_grad_da", "texture_grad_nearest", "texture_grad_linear",
+            "texture_grad_linear_mipmap_nearest", "texture_grad_linear_mipmap_linear", "antialias_grad"} <= seen

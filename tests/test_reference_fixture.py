@@ -108,3 +108,20 @@ def test_oracle_reproduces_the_reference_vectors(raw_oracle, fx):
         assert (r[..., 3] != o["peel%d" % k][..., 3]).sum() == 0
     r, rdb = o_.rasterize(i["pos"][0], i["tri"], RES, ranges=i["ranges"])
     assert (r[..., 3] != o["range_rast"][..., 3]).sum() == 0 and np.abs(r - o["range_rast"]).max() <= 1e-5
+
+
+def test_ops_transcript_replays_exactly_on_the_reference_itself(ref):
+    """tests/golden/reference_ops_transcript.{json,npz} (the calls of the reference's ops.py into _nvdiffrast_c, recorded
+    with the reference's results) replayed against the reference's own code on the CPU: the replay engine that the GPU
+    test uses against the HIP plugin must reproduce every recorded tensor bit for bit here."""
+    import numpy as np
+    from oracle import ref_torch
+    from replay_ops import replay
+    n = [0]
+
+    def on_tensor(call, idx, got, want, chained):
+        n[0] += 1
+        assert np.array_equal(got, want), (call["fn"], idx)
+
+    doc, _ = replay(ref_torch.cpu_plugin("fma"), "cpu", on_tensor)
+    assert n[0] >= 60 and doc["calls_from_fixture_scenes"] == 22
