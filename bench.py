@@ -84,7 +84,7 @@ def algorithmic_bytes(graph, P, A, T, N):
             "interp_fwd": (16 + 4 * A) * P,                     # R rast, W out
             "interp_grad": (4 * A + 16 + 16) * P,               # R dy, R rast, W g_rast
             "raster_grad": 32 * P,                              # R g_rast 16 + R rast 16
-            "interp_raster_grad": (4 * A + 16) * P,             # fused backward: R dy, R rast (g_rast never exists)
+            "interp_raster_grad": (4 * A + 16 + 16) * P,        # fused backward as the operator layer runs it: R dy, R rast, W g_rast
         }
         return per_kernel, (112 + 8 * A) * P
     C = 3
@@ -391,35 +391,13 @@ class Job:
                     "bary_max_abs_err": err(r_h[..., :3], ro[..., :3]),
                     "g_attr_max_abs_err": err(attr_s.grad.cpu().numpy(), ga_o), "g_attr_max_abs": mag(ga_o),
                     "g_pos_max_abs_err": err(pos_s.grad.cpu().numpy(), gp_o), "g_pos_max_abs": mag(gp_o)}
-        # four-op chain, one item at the config's own resolution and texture size
-        ns = 1
-        p_np, tri_np, uv_np = sc["pos"][:ns], sc["tri"], sc["uv"]
-        r, rdb = chk.rasterize(p_np, tri_np, (RES, RES))
-        uv_r, uvda_r = chk.interpolate(uv_np, r, tri_np, rdb, "all")
-        col_r = chk.texture(self.tex_np, uv_r, uvda_r, filter_mode="linear-mipmap-linear")
-        aa_r = chk.antialias(col_r, r, p_np, tri_np)
-        dy = self.G[:ns].cpu().numpy()
-        g_col, g_pos_aa = chk.antialias_grad(col_r, r, p_np, tri_np, dy)
-        g = chk.texture_grad(self.tex_np, uv_r, g_col, uvda_r, filter_mode="linear-mipmap-linear")
-        g_uvattr, g_rast, g_rdb = chk.interpolate_grad(uv_np, r, tri_np, g["uv"], rdb, g["uv_da"], "all")
-        g_pos = chk.rasterize_grad(p_np, tri_np, r, g_rast, g_rdb) + g_pos_aa
-        pos_s = torch.from_numpy(p_np).to(dev).requires_grad_(True)
-        uv_s = torch.from_numpy(uv_np).to(dev).requires_grad_(True)
-        tex_s = torch.from_numpy(self.tex_np).to(dev).requires_grad_(True)
-        rast, rast_db = dr.rasterize(self.ctx, pos_s, self.tri, (RES, RES))
-        uv, uv_da = dr.interpolate(uv_s, rast, self.tri, rast_db=rast_db, diff_attrs="all")
-        col = dr.texture(tex_s, uv, uv_da, filter_mode="linear-mipmap-linear")
-        aa = dr.antialias(col, rast, pos_s, self.tri, topology_hash=self.topo)
-        torch.autograd.backward(aa, self.G[:ns])
-        r_h = rast.detach().cpu().numpy()
-        return {"against": chk_name, "items": ns, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]),
-                "tri_id_mismatches": int((r_h[..., 3] != r[..., 3]).sum()),
-                "bary_max_abs_err": err(r_h[..., :3], r[..., :3]),
-                "col_max_abs_err": err(col.detach().cpu().numpy(), col_r),
-                "aa_max_abs_err": err(aa.detach().cpu().numpy(), aa_r),
-                "g_tex_max_abs_err": err(tex_s.grad.cpu().numpy(), g["tex"]), "g_tex_max_abs": mag(g["tex"]),
-                "g_uvattr_max_abs_err": err(uv_s.grad.cpu().numpy(), g_uvattr), "g_uvattr_max_abs": mag(g_uvattr),
-                "g_pos_max_abs_err": err(pos_s.grad.cpu().numpy(), g_pos), "g_pos_max_abs": mag(g_pos)}
+        # four-op chain, one item at the config's own resolution and texture size: every op against the reference ON THE INPUTS
+        # THE HIP PATH GAVE IT (oracle/chain.py explains why a chain through a texture is not judged end to end)
+        from oracle.chain import four_op_chain
+        res = four_op_chain(dr, self.ctx, self.topo, chk, sc["pos"][:1], sc["tri"], sc["uv"], self.tex_np, self.G[:1], (RES, RES), dev=dev)
+        res.update({"against": chk_name, "items": 1, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]),
+                    "compared": "each op on identical inputs (the HIP path's own intermediate tensors)"})
+        return res
 
     def cpu_baselines(self, cpu_items):
         """The CPU oracle (and the reference under its CPU shim) on this host's cores, bounded samples of this batch."""

@@ -130,6 +130,21 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
                           int diff_all, const int32_t* diff_attrs_host, int num_diff,
                           float* g_attr, float* g_rast, float* g_rast_db, nvdrStream_t stream);
 
+/* ---- interpolate + rasterize backward in one pass --------------------------------------
+ * Not an entry point of the reference: the work of interpolate_grad (torch_interpolate.cpp:242-248; interpolate.cu:131-274)
+ * followed by rasterize_grad (torch_rasterize.cpp:259-263; rasterize.cu:119-277) for the common graph
+ * rasterize -> interpolate (no pixel differentials), in one kernel that reads `rast` once and hands a pixel's (u, v)
+ * gradient to the rasterizer's backward in registers.
+ *   g_attr (shape of attr) and g_pos (shape of pos) must be zero-filled by the caller, as for the two separate calls;
+ *   g_rast [N,H,W,4] = what interpolate_grad would have written, or NULL to skip it (only legal when nothing else
+ *   consumes the gradient of `rast`; the operator layer always asks for it, see nvdiffrast_amd/torch/ops.py).
+ * attr_instance / attr_n as for nvdr_interpolate_grad; pos_instance != 0: pos [N,V,4], else pos [V,4] (range mode).
+ * Results equal those of the two separate calls up to the summation order of the f32 atomics. */
+int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const int32_t* tri, const float* pos,
+                                    const float* dy, int attr_instance, int attr_n, int pos_instance,
+                                    int N, int V, int A, int T, int H, int W,
+                                    float* g_attr, float* g_pos, float* g_rast, nvdrStream_t stream);
+
 /* ---- texture --------------------------------------------------------------------
  * Replaces texture_construct_mip / texture_fwd / texture_fwd_mip / texture_grad_nearest /
  * texture_grad_linear / texture_grad_linear_mipmap_nearest / texture_grad_linear_mipmap_linear

@@ -1,0 +1,279 @@
+// backward_fused.hip -- interpolate backward and rasterize backward in ONE pass over the image (gfx950).
+//
+// The metric's op graph is rasterize -> interpolate; its backward is two kernels that walk the same pixels:
+// k_interp_grad (interpolate.cu:131-274) reads rast and dy and writes g_rast = dL/d(u, v), k_raster_grad
+// (rasterize.cu:119-277) reads rast again plus that g_rast and turns it into position gradients.  Fused, a pixel's
+// (u, v) gradient goes straight from the interpolation adjoint into the pixel-shader tape in registers:
+//   * rast is read once instead of twice and g_rast is not re-read (537 MB less traffic at the headline batch),
+//   * one vertex table per 64x16-pixel block accumulates BOTH gradients of a vertex -- A attribute components and the
+//     (x, y, w) position components -- so a block's vertices are looked up, claimed and flushed once,
+//   * one launch instead of two.
+// g_rast is still WRITTEN when the caller asks for it (the operator layer does: autograd may have other consumers of
+// rast's gradient; see ops.py `_InterpolateOp.backward`) and skipped when g_rast == NULL.
+//
+// Structure = the two kernels' (DESIGN.md 4.1): phase A computes per-pixel contributions in registers and publishes
+// the block's largest magnitudes (two fixed-point scales: attribute and position contributions differ by orders of
+// magnitude), phase B sums them over runs of equal triangle id (RunScan), adds run totals to the LDS table (64-bit
+// fixed point) and flushes each touched (vertex, component) with one hardware f32 atomic.
+// Workgroup = 64 x 16 pixels, 8 waves of two rows each: the eleven per-pixel values that must survive the barrier
+// (dy[4], b0, b1 and nine position-gradient components... per row) fit 8 waves/SIMD only with two rows per wave.
+#include "nvdr_device.hpp"
+#include "nvdr_host.hpp"
+#include "nvdr_raster_tape.hpp"
+
+namespace nvdr {
+
+struct FusedParams {
+    const int* tri; const float* attr; const float* rast; const float* pos; const float* dy;
+    float* gradAttr; float* gradPos; float* gradRaster;
+    int numTriangles, numVertices, numAttr;
+    int width, height, depth;
+    int attrBC, attrInstance, posInstance, dbg;
+    float xs, xo, ys, yo;
+};
+
+constexpr int kFuBlockW = 64;
+constexpr int kFuBlockH = 16;
+constexpr int kFuWaves = 8;
+constexpr int kFuThreads = kFuWaves * 64;
+constexpr int kFuRows = kFuBlockH / kFuWaves;          // rows per wave
+
+template <int A_CT, bool WRITE_GRAST>
+__global__ __launch_bounds__(kFuThreads, 8) void k_interp_raster_grad(const FusedParams p, int slots, int gx, int gy)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    constexpr bool kRegs = (A_CT == 4 || A_CT == 2);        // upstream gradient stays in registers between the phases
+    const int A = A_CT > 0 ? A_CT : p.numAttr;
+    const int S = A + 3;                                    // table components per vertex: A attribute sums, then x, y, w
+    unsigned long long* s_vals = (unsigned long long*)s_mem;
+    uint32_t* s_keys = (uint32_t*)(s_mem + (size_t)slots * S * 8);
+    uint32_t* s_max = s_keys + slots;                       // [0] attribute max, [1] used slots, [2] position max
+    uint16_t* s_list = (uint16_t*)(s_max + 4);              // [slots] used slots (flush)
+    int bx, by, pz;
+    if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
+    VertexTable tab{s_keys, s_vals, slots, S};
+    tab.clear(threadIdx.x, kFuThreads);
+    if (threadIdx.x < 4) s_max[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = bx * kFuBlockW + lane;
+    const int row0 = by * kFuBlockH + wave * kFuRows;
+    const size_t voffA = (p.attrInstance && !p.attrBC) ? (size_t)pz * p.numVertices : 0;
+    const size_t voffP = p.posInstance ? (size_t)pz * p.numVertices : 0;
+    const float* attr = p.attr + voffA * A;
+    float* gattr = p.gradAttr + voffA * A;
+    const float4* vb = (const float4*)p.pos + voffP;
+    float* gpos = p.gradPos + voffP * 4;
+
+    int   tri[kFuRows];
+    bool  ok[kFuRows];
+    float b0[kFuRows], b1[kFuRows];
+    float4 yreg[kFuRows];
+    float g[kFuRows][9];
+    float mA = 0.f, mP = 0.f;
+
+    // ---- phase A -----------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < kFuRows; r++) {
+        const int py = row0 + r;
+        ok[r] = false; tri[r] = -1; b0[r] = 0.f; b1[r] = 0.f;
+        yreg[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 9; k++) g[r][k] = 0.f;          // the run scan multiplies masked lanes by 0: keep them finite
+        if (py >= p.height || px >= p.width) continue;
+        const size_t pidx = ((size_t)pz * p.height + py) * p.width + px;
+        const float4 rr = ((const float4*)p.rast)[pidx];
+        const int triIdx = float_to_triidx(rr.w) - 1;
+        if (triIdx < 0 || triIdx >= p.numTriangles) {
+            if (WRITE_GRAST) ((float4*)p.gradRaster)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
+        if (!indices_ok(vi0, vi1, vi2, p.numVertices))
+            continue;                                       // corrupt indices: leave untouched (interpolate.cu:163-167)
+        ok[r] = true; tri[r] = triIdx; b0[r] = rr.x; b1[r] = rr.y;
+        const float* a0 = attr + (size_t)vi0 * A;
+        const float* a1 = attr + (size_t)vi1 * A;
+        const float* a2 = attr + (size_t)vi2 * A;
+        const float4 P[3] = {vb[vi0], vb[vi1], vb[vi2]};    // in flight together with the attribute rows and dy
+        const float* pdy = p.dy + pidx * A;
+        const float bmax = fmaxf(fmaxf(fabsf(rr.x), fabsf(rr.y)), fabsf(1.f - rr.x - rr.y));
+
+        float gb0 = 0.f, gb1 = 0.f, ymax = 0.f;
+        if (A_CT == 4) {
+            const float4 y = load_streaming((const float4*)pdy);
+            const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
+            gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
+            gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
+            ymax = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y), y.z), y.w);
+            yreg[r] = y;
+        } else if (A_CT == 2) {
+            const float2 y = *(const float2*)pdy;
+            const float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
+            gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y);
+            gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y);
+            ymax = max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y);
+            yreg[r] = make_float4(y.x, y.y, 0.f, 0.f);
+        } else {
+            for (int i = 0; i < A; i++) {
+                const float y = pdy[i];
+                const float s2v = a2[i];
+                gb0 += y * (a0[i] - s2v);
+                gb1 += y * (a1[i] - s2v);
+                ymax = max_abs_keep_nan(ymax, y);
+            }
+        }
+        if (WRITE_GRAST) ((float4*)p.gradRaster)[pidx] = make_float4(gb0, gb1, 0.f, 0.f);
+        mA = max_abs_keep_nan(mA, ymax * bmax);             // >= every |b_k * dy_i| (rounding is monotone)
+
+        // rasterize backward of this pixel with (gb0, gb1) as the upstream gradient of (u, v); pixels whose upstream
+        // gradient is all +-0 contribute nothing (rasterize.cu:143-148)
+        if ((((uint32_t)(__float_as_int(gb0) | __float_as_int(gb1))) << 1) != 0u) {
+            const float fx = p.xs * (float)px + p.xo;
+            const float fy = p.ys * (float)py + p.yo;
+            raster_tape<false>(P, fx, fy, p.xs, p.ys, gb0, gb1, make_float4(0.f, 0.f, 0.f, 0.f), false, g[r]);
+#pragma unroll
+            for (int k = 0; k < 9; k++) mP = max_abs_keep_nan(mP, g[r][k]);
+        }
+    }
+    block_max_update(&s_max[0], mA);
+    block_max_update(&s_max[2], mP);
+    __syncthreads();
+    const uint32_t maxA = s_max[0], maxP = s_max[2];
+    if ((maxA | maxP) == 0u) return;                        // no contribution anywhere in the block
+    // no table (very wide vertices) / inf or NaN present in either gradient: the whole block goes through plain f32 atomics
+    const bool direct = slots == 0 || maxA >= 0x7F800000u || maxP >= 0x7F800000u;
+    const FixedScale fsA(direct || maxA == 0u ? 0x3F800000u : maxA);
+    const FixedScale fsP(direct || maxP == 0u ? 0x3F800000u : maxP);
+
+    // ---- phase B -----------------------------------------------------------------------
+    int vi[kFuRows][3];
+#pragma unroll
+    for (int r = 0; r < kFuRows; r++) {
+        const int t = ok[r] ? tri[r] : 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) vi[r][k] = p.tri[t * 3 + k];        // L1/L2 hits: cheaper than six registers across phase A
+    }
+#pragma unroll
+    for (int r = 0; r < kFuRows; r++) {
+        if (__ballot(ok[r]) == 0) continue;
+        const RunScan rs(tri[r], ok[r]);
+        const bool emit = direct ? ok[r] : rs.tail;
+        int s0 = -1, s1 = -1, s2 = -1;
+        if (emit && !direct) tab.find3(vi[r][0], vi[r][1], vi[r][2], s0, s1, s2);
+        const bool tabled = emit && (s0 | s1 | s2) >= 0;
+        const bool anyLoose = __ballot(emit && !tabled) != 0ull;
+        // attribute component i of the three vertices
+        auto put3 = [&](int i, float v0, float v1, float v2) {
+            if (tabled) { tab.add(s0, i, fsA.to_fixed(v0)); tab.add(s1, i, fsA.to_fixed(v1)); tab.add(s2, i, fsA.to_fixed(v2)); }
+            if (anyLoose && emit && !tabled) {
+                const int sl[3] = {s0, s1, s2}; const float vv[3] = {v0, v1, v2};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (sl[k] >= 0) tab.add(sl[k], i, fsA.to_fixed(vv[k]));
+                    else atomic_add_f32(gattr + (size_t)vi[r][k] * A + i, vv[k]);
+                }
+            }
+        };
+        const float c0 = ok[r] ? b0[r] : 0.f, c1 = ok[r] ? b1[r] : 0.f, c2 = ok[r] ? 1.f - b0[r] - b1[r] : 0.f;
+        const size_t pidx = ((size_t)pz * p.height + (row0 + r)) * p.width + px;
+        const float* pdy = p.dy + pidx * A;
+        for (int i = 0; i < A; i++) {
+            float y;
+            if (kRegs) y = i == 0 ? yreg[r].x : i == 1 ? yreg[r].y : i == 2 ? yreg[r].z : yreg[r].w;
+            else       y = ok[r] ? pdy[i] : 0.f;
+            float v0 = c0 * y, v1 = c1 * y, v2 = c2 * y;
+            if (!direct) rs.scan3(v0, v1, v2);
+            put3(i, v0, v1, v2);
+        }
+        // position components (x, y, w) of vertex k
+        if (maxP != 0u) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float v0 = g[r][k * 3 + 0], v1 = g[r][k * 3 + 1], v2 = g[r][k * 3 + 2];
+                if (!direct) rs.scan3(v0, v1, v2);
+                if (!emit) continue;
+                const int s = k == 0 ? s0 : k == 1 ? s1 : s2;
+                if (s >= 0) {
+                    tab.add(s, A + 0, fsP.to_fixed(v0)); tab.add(s, A + 1, fsP.to_fixed(v1)); tab.add(s, A + 2, fsP.to_fixed(v2));
+                } else {
+                    float* q = gpos + (size_t)vi[r][k] * 4;
+                    atomic_add_f32(q + 0, v0); atomic_add_f32(q + 1, v1); atomic_add_f32(q + 3, v2);
+                }
+            }
+        }
+    }
+    if (direct) return;
+
+    // Flush: one atomic per (vertex, component) this block touched; consecutive lanes take the components of one vertex.
+    __syncthreads();
+    const int n = tab.compact(s_list, &s_max[1], threadIdx.x, kFuThreads) * S;
+    for (int i = threadIdx.x; i < n; i += kFuThreads) {
+        const int u = i / S, c = i - u * S;
+        const int slot = s_list[u];
+        const unsigned long long t = s_vals[slot * S + c];
+        if (!t) continue;
+        const size_t v = (size_t)(s_keys[slot] - 1u);
+        if (c < A) atomic_add_f32(gattr + v * A + c, fsA.to_float(t));
+        else       atomic_add_f32(gpos + v * 4 + (c - A == 2 ? 3 : c - A), fsP.to_float(t));
+    }
+}
+
+}  // namespace nvdr
+
+using namespace nvdr;
+
+// LDS of one workgroup for `slots` table entries of A + 3 components: sums, key, used-list entry, header.
+static size_t fused_lds_bytes(int slots, int A) { return (size_t)slots * (8 * (size_t)(A + 3) + 6) + 16; }
+
+extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const int32_t* tri, const float* pos,
+                                               const float* dy, int attr_instance, int attr_n, int pos_instance,
+                                               int N, int V, int A, int T, int H, int W,
+                                               float* g_attr, float* g_pos, float* g_rast, nvdrStream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched
+    NVDR_REQUIRE(attr && rast && tri && pos && dy && g_attr && g_pos, "interpolate_rasterize_grad: null pointer");
+    NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "rast must have shape[>0, >0, >0, 4]");
+    NVDR_REQUIRE(T > 0, "tri must have shape [>0, 3]");
+    NVDR_REQUIRE(V > 0 && A > 0, "attr must have shape [>0, >0, >0] or [>0, >0]");
+    if (attr_instance) NVDR_REQUIRE(attr_n == N || attr_n == 1, "minibatch size mismatch between inputs rast, attr");
+    NVDR_REQUIRE(!((uintptr_t)rast & 15), "rast input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)pos & 15), "pos input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)g_rast & 15), "grad_rast output tensor not aligned to float4");
+    FusedParams p{};
+    p.tri = tri; p.attr = attr; p.rast = rast; p.pos = pos; p.dy = dy;
+    p.gradAttr = g_attr; p.gradPos = g_pos; p.gradRaster = g_rast;
+    p.numTriangles = T; p.numVertices = V; p.numAttr = A;
+    p.width = W; p.height = H; p.depth = N;
+    p.attrInstance = attr_instance ? 1 : 0;
+    p.attrBC = (attr_instance && attr_n == 1) ? 1 : 0;
+    p.posInstance = pos_instance ? 1 : 0;
+    p.dbg = debug_flags();
+    p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
+    p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
+    const int gx = (W + kFuBlockW - 1) / kFuBlockW, gy = (H + kFuBlockH - 1) / kFuBlockH;
+    const long long total = (long long)gx * gy * N;
+    NVDR_REQUIRE(total < (1ll << 30), "interpolate_rasterize_grad: too many pixel blocks");
+    dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kFuThreads);
+    // LDS vertex table: as many power-of-two slots as fit in 32 KiB (four 8-wave workgroups per CU), at most 512;
+    // none (plain atomics) for vertices too wide for even 32 slots in 64 KiB
+    int slots = 512;
+    while (slots > 32 && fused_lds_bytes(slots, A) > 32 * 1024) slots >>= 1;
+    if (fused_lds_bytes(slots, A) > 64 * 1024) slots = 0;
+    const size_t lds = fused_lds_bytes(slots, A);
+    const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);
+    const bool vec2 = (A == 2) && !((uintptr_t)attr & 7) && !((uintptr_t)dy & 7);
+    {
+        ProfileScope ps("interp_raster_grad", stream);
+#define NVDR_FUSED(ACT)                                                                                                    \
+    do {                                                                                                                    \
+        if (g_rast) hipLaunchKernelGGL((k_interp_raster_grad<ACT, true>),  grid, block, lds, stream, p, slots, gx, gy);    \
+        else        hipLaunchKernelGGL((k_interp_raster_grad<ACT, false>), grid, block, lds, stream, p, slots, gx, gy);    \
+    } while (0)
+        if (vec4) NVDR_FUSED(4); else if (vec2) NVDR_FUSED(2); else NVDR_FUSED(0);
+    }
+    NVDR_LAUNCH_CHECK();
+    return NVDR_OK;
+}

@@ -33,6 +33,29 @@ def set_cube_corner_fix(enable):
     _capi.check(_capi.load().nvdr_set_option(_capi.OPT_CUBE_CORNER_FIX, int(bool(enable))), "set_cube_corner_fix")
 
 
+# Fused backward of rasterize -> interpolate (ops.py `_RasterOrigin`): "auto" = prepare the position gradient inside
+# interpolate's backward kernel and use it when autograd shows that nothing else contributed to rast's gradient;
+# "off" = always the two separate kernels of the reference's structure.
+_fused = {"mode": "auto", "used": 0, "discarded": 0}
+
+
+def set_fused_backward(mode):
+    """Not in the reference.  "auto" (default) or "off"."""
+    assert mode in ("auto", "off")
+    _fused["mode"] = mode
+
+
+def fused_backward_mode():
+    return _fused["mode"]
+
+
+def fused_backward_count(what=None):
+    """Counts how often a prepared position gradient was used / discarded (tests); without argument returns both."""
+    if what is None:
+        return {"used": _fused["used"], "discarded": _fused["discarded"]}
+    _fused[what] += 1
+
+
 def _is_capturing(device):
     return torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
 
@@ -142,6 +165,7 @@ class RasterizeCRStateWrapper:
         self.cuda_device_idx = int(cuda_device_idx)
         self.scratch = None
         self.clean_layout = None
+        self.fused_disabled = False   # ops.py: a prepared fused backward was discarded once on this context -> stop preparing
         self.captured = False    # some call of this context was recorded into a hipGraph
         self.retired = []        # scratch buffers that recorded graphs still point to
         self.reported_bytes = 0
@@ -461,6 +485,48 @@ def interpolate_grad(attr, rast, tri, dy):
     """torch_interpolate.cpp:242-248."""
     g_attr, g_rast, _ = interpolate_grad_da(attr, rast, tri, dy, None, None, False, [])
     return g_attr, g_rast
+
+
+def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True):
+    """Not in the reference's module: interpolate_grad (torch_interpolate.cpp:242-248) and rasterize_grad
+    (torch_rasterize.cpp:259-263) of the graph rasterize -> interpolate in ONE kernel (csrc/backward_fused.hip).
+    -> (g_attr, g_rast or None, g_pos), equal to
+        g_attr, g_rast = interpolate_grad(attr, rast, tri, dy);  g_pos = rasterize_grad(pos, tri, rast, g_rast)
+    up to the summation order of the atomics.  `with_g_rast=False` skips writing g_rast (only legal when nothing else
+    consumes the gradient of rast).  attr and pos must index the same vertices with the same `tri`."""
+    fn = "interpolate_rasterize_grad"
+    dev = _check_device(fn, attr=attr, rast=rast, tri=tri, pos=pos, dy=dy)
+    _check_contiguous(fn, attr=attr, rast=rast, tri=tri, pos=pos)
+    _check_f32(fn, attr=attr, rast=rast, pos=pos, dy=dy)
+    _check_i32(fn, tri=tri)
+    attr_instance = attr.dim() > 2
+    pos_instance = pos.dim() > 2
+    _require(rast.dim() == 4 and rast.size(0) > 0 and rast.size(1) > 0 and rast.size(2) > 0 and rast.size(3) == 4, fn,
+             "rast must have shape[>0, >0, >0, 4]")
+    _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
+    _require(attr.dim() in (2, 3) and attr.size(0) > 0 and attr.size(1) > 0 and (attr.dim() == 2 or attr.size(2) > 0), fn,
+             "attr must have shape [>0, >0, >0] or [>0, >0]")
+    N, H, W = rast.size(0), rast.size(1), rast.size(2)
+    if pos_instance:
+        _require(pos.dim() == 3 and pos.size(0) == N and pos.size(1) > 0 and pos.size(2) == 4, fn, "pos must have shape [depth, >0, 4]")
+    else:
+        _require(pos.dim() == 2 and pos.size(0) > 0 and pos.size(1) == 4, fn, "pos must have shape [>0, 4]")
+    attr_depth = attr.size(0) if attr_instance else 1
+    V = attr.size(1 if attr_instance else 0)
+    A = attr.size(2 if attr_instance else 1)
+    _require(V == pos.size(1 if pos_instance else 0), fn, "attr and pos must have the same number of vertices")
+    _require(dy.dim() == 4 and tuple(dy.shape) == (N, H, W, A), fn, "dy must have shape [depth, height, width, attributes]")
+    _require(attr_depth == N or attr_depth == 1, fn, "minibatch size mismatch between inputs rast, dy, attr")
+    dy_ = dy.contiguous()
+    with _on_device(dev):
+        g_attr = torch.zeros_like(attr)
+        g_pos = torch.zeros_like(pos)
+        g_rast = torch.empty_like(rast) if with_g_rast else None
+        rc = _capi.load().nvdr_interpolate_rasterize_grad(attr.data_ptr(), rast.data_ptr(), tri.data_ptr(), pos.data_ptr(), dy_.data_ptr(),
+                                                          int(attr_instance), attr_depth, int(pos_instance), N, V, A, tri.size(0), H, W,
+                                                          g_attr.data_ptr(), g_pos.data_ptr(), _capi.ptr(g_rast), _stream(dev))
+    _capi.check(rc, fn)
+    return g_attr, g_rast, g_pos
 
 
 # ----------------------------------------------------------------------------- texture

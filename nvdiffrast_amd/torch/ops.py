@@ -104,17 +104,63 @@ class _Dispatch(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class _RasterOrigin:
+    """What a `rast` tensor remembers about the rasterize call that produced it, for the fused backward pass.
+
+    The metric's graph is rasterize -> interpolate.  Its backward is two kernels over the same pixels; the library has
+    one kernel that does both (csrc/backward_fused.hip, `_plugin.interpolate_rasterize_grad`).  Whether the fused result
+    may be USED is only known when autograd delivers rast's gradient to the rasterize node: if interpolate was the sole
+    contributor, the tensor that arrives is the very g_rast interpolate returned (same storage, same version counter);
+    if anything else contributed (antialias does not, but user code such as a mask made from rast does), autograd has
+    summed the contributions into another tensor.  So interpolate's backward computes g_attr, g_rast AND the position
+    gradient in one pass, returns g_rast as usual -- always a correct gradient -- and leaves the position gradient here;
+    rasterize's backward takes it when the tensor it receives is that g_rast, and otherwise computes the gradient from
+    what it did receive, as if nothing had been prepared (the context then stops preparing: `fused_disabled`)."""
+    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "interpolations", "pending")
+
+    def __init__(self, pos, tri, state, rast):
+        self.pos, self.tri, self.state = pos, tri, state
+        self.rast_ptr, self.rast_version = rast.data_ptr(), rast._version
+        self.interpolations = 0            # interpolate() calls that took this rast
+        self.pending = None                # (g_rast, its data_ptr, its version, g_pos) between the two backward nodes
+
+    def usable_by(self, attr, rast, tri):
+        """interpolate(attr, rast, tri) may prepare the position gradient: this very rast, untouched, the same triangle
+        tensor (pose-style scripts interpolate with another index buffer), one vertex set, nobody else doing the same."""
+        st = self.state
+        return (_plugin.fused_backward_mode() == "auto" and not st.fused_disabled and self.pending is None
+                and self.interpolations == 1 and rast.requires_grad
+                and rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version
+                and tri.data_ptr() == self.tri.data_ptr() and tri.shape == self.tri.shape
+                and attr.shape[-2] == self.pos.shape[-2])
+
+
 class _RasterizeOp:
     """args: context, pos, tri, resolution, ranges, grad_db, peeling_idx -> (rast, rast_db); gradient to pos only."""
 
     @staticmethod
     def forward(raster_ctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
-        rast, rast_db = _plugin.rasterize_fwd_cuda(raster_ctx.cpp_wrapper, pos, tri, resolution, ranges, peeling_idx)
-        return (rast, rast_db), (pos, tri, rast), bool(grad_db)
+        state = raster_ctx.cpp_wrapper
+        rast, rast_db = _plugin.rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx)
+        origin = None
+        if pos.requires_grad and not state.fused_disabled:
+            origin = rast._nvdr_origin = _RasterOrigin(pos, tri, state, rast)
+        return (rast, rast_db), (pos, tri, rast), (bool(grad_db), origin)
 
     @staticmethod
-    def backward(grad_db, saved, d_rast, d_rast_db):
+    def backward(state, saved, d_rast, d_rast_db):
+        grad_db, origin = state
         pos, tri, rast = saved
+        if origin is not None and origin.pending is not None:
+            (g_rast, ptr, version, g_pos), origin.pending = origin.pending, None
+            if (d_rast is not None and (d_rast_db is None or not grad_db)
+                    and d_rast.data_ptr() == ptr and d_rast._version == version and d_rast.shape == g_rast.shape):
+                _plugin.fused_backward_count("used")
+                return None, g_pos, None, None, None, None, None
+            # rast's gradient has other contributors in this program: what was prepared is void, and preparing it again
+            # on this context would be wasted work every step
+            _plugin.fused_backward_count("discarded")
+            origin.state.fused_disabled = True
         if d_rast is None:
             if not grad_db:
                 return (None,) * 7
@@ -138,23 +184,36 @@ class _InterpolateOp:
         else:
             outs = _plugin.interpolate_fwd(attr, rast, tri)
             keep = (attr, rast, tri)
-        return tuple(outs), keep, (with_da, diff_all, diff_list)
+        origin = getattr(rast, "_nvdr_origin", None)     # set by rasterize() on its own output (fused backward)
+        if origin is not None:
+            origin.interpolations += 1
+        return tuple(outs), keep, (with_da, diff_all, diff_list, origin)
+
+    @staticmethod
+    def _plain_grad(attr, rast, tri, d_out, origin):
+        """Gradient without pixel differentials; with the position gradient prepared in the same pass when the rast
+        came straight from rasterize() and this is its only interpolation (see _RasterOrigin)."""
+        if origin is not None and origin.usable_by(attr, rast, tri):
+            g_attr, g_rast, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out)
+            origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos)
+            return g_attr, g_rast
+        return _plugin.interpolate_grad(attr, rast, tri, d_out)
 
     @staticmethod
     def backward(state, saved, d_out, d_out_da):
-        with_da, diff_all, diff_list = state
+        with_da, diff_all, diff_list, origin = state
         if d_out is None:
             d_out = torch.zeros(tuple(saved[1].shape[:3]) + (saved[0].shape[-1],), dtype=saved[0].dtype, device=saved[0].device)
         if with_da and d_out_da is None:                 # differentials computed but unused: the plain gradient is the same
             attr, rast, tri, _rast_db = saved
-            g_attr, g_rast = _plugin.interpolate_grad(attr, rast, tri, d_out)
+            g_attr, g_rast = _InterpolateOp._plain_grad(attr, rast, tri, d_out, origin)
             return g_attr, g_rast, None, None, None, None
         if with_da:
             attr, rast, tri, rast_db = saved
             g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list)
             return g_attr, g_rast, None, g_rast_db, None, None
         attr, rast, tri = saved
-        g_attr, g_rast = _plugin.interpolate_grad(attr, rast, tri, d_out)
+        g_attr, g_rast = _InterpolateOp._plain_grad(attr, rast, tri, d_out, origin)
         return g_attr, g_rast, None, None, None, None
 
 
