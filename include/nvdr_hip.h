@@ -179,12 +179,18 @@ int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_host, int L,
  * g_mip_level_bias [N,H,W] (linear-mipmap-linear only, NULL when the input is absent) are fully
  * written.  pull_mip_grads != 0 folds the level gradients into g_tex afterwards (the internal mip
  * chain, torch_texture.cpp:679-687); custom stacks keep their own gradients. */
+/* scratch (optional, NULL = none; nvdr_texture_grad_scratch_bytes(N, H, W, C) bytes, 4-byte aligned, contents irrelevant):
+ * with it, pixels that share one texel quad wave by wave -- a rendered image's background, where interpolate() leaves
+ * uv = 0 -- are reduced in two levels (per-wave records, then a fold kernel) instead of one flush per 16x16-pixel block
+ * into the same four texels; results are the same up to the order of the f32 sums. */
+size_t nvdr_texture_grad_scratch_bytes(int N, int H, int W, int C);
 int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_host, int L,
                       const float* uv, const float* uv_da, const float* mip_level_bias, const float* dy,
                       int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
                       int filter_mode, int boundary_mode, int pull_mip_grads,
                       float* g_tex, float* const* g_mip_ptrs_host,
-                      float* g_uv, float* g_uv_da, float* g_mip_level_bias, nvdrStream_t stream);
+                      float* g_uv, float* g_uv_da, float* g_mip_level_bias,
+                      void* scratch, size_t scratch_bytes, nvdrStream_t stream);
 
 /* ---- antialias ------------------------------------------------------------------
  * Replaces antialias_construct_topology_hash / antialias_fwd / antialias_grad

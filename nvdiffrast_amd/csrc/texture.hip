@@ -33,7 +33,16 @@ struct TexParams {
     int boundary, channels, imgW, imgH, n, texW, texH, texDepth, levelMax;
     int tilesX, tilesY, dbg;
     int cornerFix;                  // NVDR_OPT_CUBE_CORNER_FIX: keep the cube-corner flag for texture slices >= 1
+    // Gradient pass, caller-provided scratch (NULL = none): one record per WAVE of pixels that all sample the same texel
+    // quad of level 0 with a zero footprint (k_tex_grad's uniform-wave path): rec[0..3][r] = texel index of each tap
+    // (-1: none; rec[0][r] = -1 also marks "no record", the state the host puts the array in before the launch),
+    // rec[4..7][r] = the taps' bilinear weights, rec[8..8+C)[r] = the wave's summed upstream gradient per channel.
+    // k_tex_grad_fold merges the records (a constant-uv background produces ONE texel quad for hundreds of thousands of
+    // waves) and adds the totals to the gradient texture.
+    int* rec; int nrec;
 };
+
+constexpr int kTexRecHeader = 8;                  // words per record in front of the channel totals
 
 __device__ __forceinline__ int level_dim(int d, int level) { int v = d >> level; return v > 1 ? v : 1; }
 
@@ -744,21 +753,56 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
         const float tw0[4] = {w000, w010, w001, w011};
         const float sclu0 = (float)p.texW, sclv0 = (float)p.texH;
+        // With scratch from the caller the wave's totals leave as ONE record (merged by k_tex_grad_fold after this kernel):
+        // a background of constant uv would otherwise send one flush per 16x16-pixel block -- 100 k workgroups at config 3 --
+        // to the same four texels, where same-address f32 atomics execute one after another (half of that case's time).
+        const bool toRecord = p.rec != nullptr;
+        int* recBase = nullptr;
+        if (toRecord) {
+            const int blk = (int)(blockIdx.x & 7) * ((p.tilesX * p.tilesY * p.n + 7) >> 3) + (int)(blockIdx.x >> 3);     // as tex_pixel
+            recBase = p.rec + (blk * 4 + (int)(threadIdx.x >> 6));
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    recBase[(size_t)(4 + k) * p.nrec] = __float_as_int(tw0[k]);
+                    if (k > 0) recBase[(size_t)k * p.nrec] = q0.tc[k];
+                }
+            }
+        }
         int sl0[4] = {-1, -1, -1, -1};
-        if (lane == 63) slots_of(q0, 0, sl0);
+        if (lane == 63 && !toRecord) slots_of(q0, 0, sl0);
         float gu = 0.f, gv = 0.f;
         for (int c = 0; c < C; c++) {
             const float d = pDy[c];
             const float tot = wave_sum_to_last(d);                       // valid in lane 63
             if (lane == 63) {
+                if (toRecord) recBase[(size_t)(kTexRecHeader + c) * p.nrec] = __float_as_int(tot);
+                else {
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const float v = tw0[k] * tot; scatter(sl0[k], c, v); spill(sl0[k], 0, q0.tc[k], c, v); }
+                    for (int k = 0; k < 4; k++) { const float v = tw0[k] * tot; scatter(sl0[k], c, v); spill(sl0[k], 0, q0.tc[k], c, v); }
+                }
             }
             float a[4];
             fetch_quad(pIn0, q0, C, c, a);
             const float ad = (a[3] + a[0] - a[1] - a[2]);
             gu += d * ((a[1] - a[0]) + q0.fv * ad) * sclu0;
             gv += d * ((a[2] - a[0]) + q0.fu * ad) * sclv0;
+        }
+        // tap 0's index makes the record valid (taps without a texel -- boundary mode zero -- carry -1 and weight anything;
+        // a record whose FIRST tap has no texel is stored with the first valid tap moved to the front)
+        if (toRecord && lane == 63) {
+            int first = q0.tc[0];
+            if (first < 0) {
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    if (first < 0 && q0.tc[k] >= 0) {
+                        first = q0.tc[k];
+                        recBase[(size_t)4 * p.nrec] = __float_as_int(tw0[k]);
+                        recBase[(size_t)k * p.nrec] = -1;
+                    }
+                }
+            }
+            recBase[0] = first;                                           // stays -1 when no tap has a texel
         }
         ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
         if (FILTER == TEX_LML) {
@@ -929,6 +973,88 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
         atomic_add_f32(p.gradTex[level] + ((tz * h + y) * w + x) * C + c, fs.to_float(t));
     }
+}
+
+// Second level of the gradient reduction for constant-uv regions: merges the per-wave records of k_tex_grad (TexParams::rec)
+// and adds the totals to level 0 of the gradient texture.  One wave walks kFoldPerWave consecutive records, 64 at a time;
+// while the records it sees carry the same texel quad -- the rule: neighbouring waves of a background -- their
+// weight x total products are summed over the lanes (DPP) and kept in the last lane's registers, and only a change of
+// quad, or the end of the walk, costs 4 x C atomics.  Groups of 64 records with mixed quads (region borders) are added
+// record by record.  Order of the f32 sums: lanes in a DPP tree, then groups in sequence -- deterministic.
+constexpr int kFoldPerWave = 64 * 8;
+
+template <int C_CT>
+__global__ __launch_bounds__(256) void k_tex_grad_fold(const int* __restrict__ rec, int nrec, int channels, float* __restrict__ gradTex)
+{
+    const int C = C_CT > 0 ? C_CT : channels;
+    constexpr int CMAX = C_CT > 0 ? C_CT : 8;                 // generic instantiation: up to 8 channels in registers, more record by record
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int begin = wave * kFoldPerWave, end = min(begin + kFoldPerWave, nrec);
+    if (begin >= nrec) return;
+    int run[4] = {-1, -1, -1, -1};                            // the quad being accumulated (valid in every lane: it is wave-uniform)
+    float acc[4][CMAX];                                       // its totals (lane 63)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) acc[k][c] = 0.f;
+    auto flush = [&]() {
+        if (run[0] >= 0 && lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (run[k] >= 0)
+                    for (int c = 0; c < min(C, CMAX); c++)
+                        if (acc[k][c] != 0.f) atomic_add_f32(gradTex + (size_t)run[k] * C + c, acc[k][c]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) acc[k][c] = 0.f;
+    };
+    for (int r0 = begin; r0 < end; r0 += 64) {
+        const int r = r0 + lane;
+        int t[4] = {-1, -1, -1, -1};
+        if (r < end) {
+            t[0] = rec[r];
+            if (t[0] >= 0) { t[1] = rec[(size_t)nrec + r]; t[2] = rec[(size_t)2 * nrec + r]; t[3] = rec[(size_t)3 * nrec + r]; }
+        }
+        const bool valid = t[0] >= 0;
+        const uint64_t vm = __ballot(valid);
+        if (vm == 0ull) continue;
+        const int src = __builtin_ctzll(vm);
+        int f[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) f[k] = __builtin_amdgcn_readlane(t[k], src);
+        const bool same = !valid || ((t[0] == f[0]) & (t[1] == f[1]) & (t[2] == f[2]) & (t[3] == f[3]));
+        const bool uniform = (__ballot(same) == ~0ull) && C <= CMAX;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = __int_as_float(rec[(size_t)(4 + k) * nrec + r]);
+        }
+        if (uniform) {
+            if ((f[0] != run[0]) | (f[1] != run[1]) | (f[2] != run[2]) | (f[3] != run[3])) {
+                flush();
+#pragma unroll
+                for (int k = 0; k < 4; k++) run[k] = f[k];
+            }
+            for (int c = 0; c < min(C, CMAX); c++) {
+                const float tot = valid ? __int_as_float(rec[(size_t)(kTexRecHeader + c) * nrec + r]) : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    acc[k][c] += wave_sum_to_last(w[k] * tot);                // valid in lane 63
+                }
+            }
+        } else if (valid) {
+            for (int c = 0; c < C; c++) {
+                const float tot = __int_as_float(rec[(size_t)(kTexRecHeader + c) * nrec + r]);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (t[k] >= 0) atomic_add_f32(gradTex + (size_t)t[k] * C + c, w[k] * tot);
+            }
+        }
+    }
+    flush();
 }
 
 // ---- mip construction / mip gradient pull ------------------------------------------------------
@@ -1324,12 +1450,22 @@ extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_h
     return NVDR_OK;
 }
 
+// Records of the two-level reduction: one per wave of pixels = four per 16x16-pixel block, 8 + C words each.
+static long long tex_grad_records(int N, int H, int W) { return 4ll * ((W + 15) / 16) * ((H + 15) / 16) * N; }
+
+extern "C" size_t nvdr_texture_grad_scratch_bytes(int N, int H, int W, int C)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return (size_t)tex_grad_records(N, H, W) * (size_t)(kTexRecHeader + C) * 4;
+}
+
 extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_host, int L,
                                  const float* uv, const float* uv_da, const float* mip_level_bias, const float* dy,
                                  int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
                                  int filter_mode, int boundary_mode, int pull_mip_grads,
                                  float* g_tex, float* const* g_mip_ptrs_host,
-                                 float* g_uv, float* g_uv_da, float* g_mip_level_bias, nvdrStream_t stream_)
+                                 float* g_uv, float* g_uv_da, float* g_mip_level_bias,
+                                 void* scratch, size_t scratch_bytes, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     TexParams p;
@@ -1365,6 +1501,16 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
     while (groups >= 16 && (size_t)groups * (8 + 64 * (size_t)C) + 16 > 26 * 1024) groups >>= 1;
     if (groups < 16 || tex_w > 32768 || (long long)tex_h * (cube ? 6 : 1) > 65536 || (debug_flags() & 256)) groups = 0;   // key format
     const size_t lds = (size_t)groups * (8 + 64 * (size_t)C) + 16;         // 16 texels x C sums + key 4 B + used-list entry 4 B per patch
+    // Second reduction level for constant-uv regions (TexParams::rec), when the caller brought scratch and the kernel has
+    // a uniform-wave path for this mode (2-D, bilinear footprint, level from uv_da) and a table to fall back on.
+    const long long nrec = tex_grad_records(N, H, W);
+    const bool records = scratch && groups > 0 && !cube && filter_mode != TEX_NEAREST && !bo && !(debug_flags() & 16384)
+                         && scratch_bytes >= nvdr_texture_grad_scratch_bytes(N, H, W, C) && nrec < (1ll << 31) / (kTexRecHeader + C);
+    if (records) {
+        NVDR_REQUIRE(!((uintptr_t)scratch & 3), "texture_grad: scratch must be 4-byte aligned");
+        p.rec = (int*)scratch; p.nrec = (int)nrec;
+        NVDR_HIP_CHECK(hipMemsetAsync(scratch, 0xFF, (size_t)nrec * 4, stream));           // "no record" in every first-tap slot
+    }
     {
         ProfileScope ps("tex_grad", stream);
 #define NVDR_TEX_GRAD_C(FILTER, BO, CUBE, CC) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, CUBE, CC>), grid, dim3(256), lds, stream, p, groups)
@@ -1384,6 +1530,16 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
         }
     }
     NVDR_LAUNCH_CHECK();
+    if (records) {
+        ProfileScope ps("tex_grad_fold", stream);
+        const dim3 fgrid((unsigned)((nrec + 4ll * kFoldPerWave - 1) / (4ll * kFoldPerWave)));
+        if (C == 1)      hipLaunchKernelGGL(k_tex_grad_fold<1>, fgrid, dim3(256), 0, stream, p.rec, p.nrec, C, g_tex);
+        else if (C == 2) hipLaunchKernelGGL(k_tex_grad_fold<2>, fgrid, dim3(256), 0, stream, p.rec, p.nrec, C, g_tex);
+        else if (C == 3) hipLaunchKernelGGL(k_tex_grad_fold<3>, fgrid, dim3(256), 0, stream, p.rec, p.nrec, C, g_tex);
+        else if (C == 4) hipLaunchKernelGGL(k_tex_grad_fold<4>, fgrid, dim3(256), 0, stream, p.rec, p.nrec, C, g_tex);
+        else             hipLaunchKernelGGL(k_tex_grad_fold<0>, fgrid, dim3(256), 0, stream, p.rec, p.nrec, C, g_tex);
+        NVDR_LAUNCH_CHECK();
+    }
     if (pull_mip_grads && p.levelMax > 0) {                                  // torch_texture.cpp:679-687
         MipGradParams mg;
         for (int i = 0; i <= p.levelMax; i++) mg.gradTex[i] = p.gradTex[i];

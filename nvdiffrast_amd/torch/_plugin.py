@@ -532,6 +532,7 @@ def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True):
 # ----------------------------------------------------------------------------- texture
 
 _TEX_MAX_LEVELS = 17
+_TEX_GRAD_SCRATCH = True      # texture_grad_*: bring scratch for the two-level reduction of constant-uv regions (tests switch it off)
 _FILTER_NEAREST, _FILTER_LINEAR, _FILTER_LMN, _FILTER_LML = 0, 1, 2, 3
 _BOUNDARY_CUBE = 0
 
@@ -741,13 +742,19 @@ def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wr
                     g_uv_da = torch.empty_like(uv_da)
                 if has_bias:
                     g_bias = torch.empty_like(mip_level_bias)
+        # scratch for the two-level reduction of constant-uv regions (include/nvdr_hip.h); not worth a second launch for
+        # images of a few blocks
+        lib = _capi.load()
+        scratch = None
+        if _TEX_GRAD_SCRATCH and filter_mode != _FILTER_NEAREST and boundary_mode != _BOUNDARY_CUBE and n * H * W >= 4096:
+            scratch = torch.empty((lib.nvdr_texture_grad_scratch_bytes(n, H, W, C) // 4,), dtype=torch.int32, device=dev)
         rc = _capi.load().nvdr_texture_grad(tex.data_ptr(), ptrs, L, uv.data_ptr(),
                                             uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
                                             mip_level_bias.data_ptr() if (enable_mip and has_bias) else None,
                                             dy_.data_ptr(), tn, th, tw, C, n, H, W,
                                             int(filter_mode), int(boundary_mode), int(enable_mip and not has_stack),
                                             g_tex.data_ptr(), gptrs, _capi.ptr(g_uv), _capi.ptr(g_uv_da), _capi.ptr(g_bias),
-                                            _stream(dev))
+                                            _capi.ptr(scratch), 0 if scratch is None else scratch.numel() * 4, _stream(dev))
     _capi.check(rc, fn)
     return g_tex, g_uv, g_uv_da, g_bias, (g_levels if has_stack else [])
 

@@ -60,9 +60,11 @@ def test_default_run_carries_the_other_baseline_configs():
     assert p3["resolution"] == [1024, 1024] and p3["texture"] == [2048, 2048]
     for k in ("uv", "col", "aa"):
         assert p3[k + "_err"] <= 1e-5, (k, p3[k + "_err"])
-    for k in ("rast_db", "uv_da", "g_col", "g_tex", "g_uv", "g_uv_da", "g_uvattr", "g_rast", "g_rast_db"):
+    for k in ("rast_db", "uv_da", "g_col", "g_uv", "g_uv_da", "g_rast", "g_rast_db"):
         assert p3[k + "_err"] <= 1e-5 * max(1.0, p3[k + "_max"]), (k, p3[k + "_err"], p3[k + "_max"])
-    assert p3["g_pos_err"] <= 2e-5 * max(1.0, p3["g_pos_max"])                       # the sum of two ops' gradients
+    for k in ("g_tex", "g_uvattr"):      # sums of up to 6e5 terms against the reference's own f32 atomic sums (test_gpu_reference_direct.py)
+        assert p3[k + "_err"] <= 2e-5 * max(1.0, p3[k + "_max"]), (k, p3[k + "_err"], p3[k + "_max"])
+    assert p3["g_pos_err"] <= 4e-5 * max(1.0, p3["g_pos_max"])                       # the sum of two ops' summed gradients
     assert cf["c2"]["batch"] == 16 and cf["c3"]["batch"] == 32
     assert cf["c5_standin"]["iters_per_s"] > 0 and cf["c5_standin"]["loss_last"] < cf["c5_standin"]["loss_first"]
 

@@ -87,12 +87,16 @@ def test_four_op_chain_against_the_reference(dr, ref):
     within("chain vs ref: g_pos", pos.grad.cpu().numpy(), g_pos, grad_tol(g_pos, CHAIN_OPS))
 
 
-def test_four_op_chain_at_config3_scale_against_the_reference(dr, ref):
+def test_four_op_chain_at_config3_scale_against_the_reference(dr, ref, raw_oracle):
     """BASELINE configs[2] at ITS OWN size: one item at 1024^2 of the 10k-triangle benchmark mesh with a
     2048^2 mipmapped texture, the four ops forward and backward, against the reference itself (about 5 s of CPU).  Every op
     is compared ON THE INPUTS THE HIP PATH GAVE IT, with the single-op bars: a chain through a 2048^2 white-noise texture is
     not defined end to end (oracle/chain.py: a few hundred of the million pixels lie within an ulp of a texel boundary,
-    where the uv gradient of bilinear sampling jumps) -- the end-to-end differences are printed, not asserted."""
+    where the uv gradient of bilinear sampling jumps) -- the end-to-end differences are printed, not asserted.
+    Gradients that are sums over very many pixels (the texture gradient of the four texels every background pixel hits:
+    6e5 terms each) are held to 1e-5 against the oracle, which sums in f64, and to 2e-5 against the reference, whose own
+    f32 atomic sum in launch order carries a rounding noise of that size (the bracket oracle/pinned.py uses to pin one
+    to the other)."""
     from oracle.chain import four_op_chain
     rng = np.random.default_rng(5)
     res = (1024, 1024)
@@ -101,14 +105,19 @@ def test_four_op_chain_at_config3_scale_against_the_reference(dr, ref):
     tex_np = rng.uniform(size=(1, 2048, 2048, 3)).astype(np.float32)
     dy = _t(rng.normal(size=(1,) + res + (3,)).astype(np.float32))
     ctx = dr.RasterizeCudaContext()
-    e = four_op_chain(dr, ctx, None, ref, b["pos"], b["tri"], b["uv"], tex_np, dy, res)
-    assert e["tri_id_mismatches"] == 0 and e["coverage"] > 0.1
-    print("c3-scale chain, end to end (conditioning, not parity):", e["end_to_end"])
-    for k in ("bary_max_abs", "uv", "col", "aa"):
-        within("c3 chain, op by op: " + k, e[k + "_err"], 0.0, ATOL)
-    for k in ("rast_db", "uv_da", "g_col", "g_tex", "g_uv", "g_uv_da", "g_uvattr", "g_rast", "g_rast_db"):
-        within("c3 chain, op by op: " + k, e[k + "_err"], 0.0, ATOL * max(1.0, e[k + "_max"]))
-    within("c3 chain, op by op: g_pos", e["g_pos_err"], 0.0, 2 * ATOL * max(1.0, e["g_pos_max"]))       # sum of two ops' gradients
+    for chk, who, summed in ((ref, "ref", 2.0), (raw_oracle, "oracle", 1.0)):
+        e = four_op_chain(dr, ctx, None, chk, b["pos"], b["tri"], b["uv"], tex_np, dy, res, end_to_end=(who == "ref"))
+        assert e["tri_id_mismatches"] == 0 and e["coverage"] > 0.1
+        if who == "ref":
+            print("c3-scale chain, end to end (conditioning, not parity):", e["end_to_end"])
+        name = "c3 chain vs %s, op by op: " % who
+        for k in ("bary_max_abs", "uv", "col", "aa"):
+            within(name + k, e[k + "_err"], 0.0, ATOL)
+        for k in ("rast_db", "uv_da", "g_col", "g_uv", "g_uv_da", "g_rast", "g_rast_db"):            # per-pixel results
+            within(name + k, e[k + "_err"], 0.0, ATOL * max(1.0, e[k + "_max"]))
+        for k in ("g_tex", "g_uvattr"):                                                              # sums over many pixels
+            within(name + k, e[k + "_err"], 0.0, summed * ATOL * max(1.0, e[k + "_max"]))
+        within(name + "g_pos", e["g_pos_err"], 0.0, 2 * summed * ATOL * max(1.0, e["g_pos_max"]))   # two ops' sums added
 
 
 @pytest.mark.parametrize("fix", [False, True])

@@ -346,3 +346,52 @@ def test_texture_backward_on_constant_uv_regions(dr, oracle, fm, bm):
     if fm == "linear-mipmap-linear":
         _close(t_da.grad.cpu().numpy(), g["uv_da"], _tol(g["uv_da"]))
         _close(t_bias.grad.cpu().numpy(), g["mip_level_bias"], _tol(g["mip_level_bias"]))
+
+
+@pytest.mark.parametrize("bm", ["wrap", "clamp", "zero"])
+@pytest.mark.parametrize("C,tex_n", [(3, 1), (4, 2), (1, 1), (6, 1)])
+def test_texture_backward_two_level_reduction_of_constant_regions(dr, oracle, bm, C, tex_n):
+    """k_tex_grad with caller scratch (include/nvdr_hip.h): waves whose pixels share one texel quad leave per-wave records,
+    k_tex_grad_fold merges them.  Several constant regions with different quads (runs that change inside a fold wave's
+    walk), region borders through waves, a region whose footprint lies outside a zero-boundary texture (first tap without
+    a texel, or none at all), zero upstream gradients, and the result with the scratch withheld (one-level path) next to it."""
+    from nvdiffrast_amd.torch import _plugin
+    rng = np.random.default_rng(400 + C)
+    N, H, W = max(2, tex_n), 176, 208
+    tex = rng.uniform(size=(tex_n, 32, 64, C)).astype(np.float32)
+    uv = rng.uniform(-0.2, 1.2, size=(N, H, W, 2)).astype(np.float32)
+    uv_da = (rng.normal(size=(N, H, W, 4)) * 0.05).astype(np.float32)
+
+    def flat(n, ys, xs, u, v):
+        uv[n, ys, xs] = np.array([u, v], np.float32); uv_da[n, ys, xs] = 0.0
+    flat(0, slice(0, 176), slice(0, 160), 0.0, 0.0)            # background: quad around texel corner (0, 0)
+    flat(0, slice(40, 90), slice(30, 100), 0.37, 0.61)         # another constant inside it (borders cut through 8x8 wave tiles)
+    flat(1, slice(0, 64), slice(0, 208), -0.004, 0.5)          # left of the texture: first tap has no texel under 'zero'
+    flat(1, slice(64, 128), slice(0, 208), -0.7, -0.7)         # far outside: no tap has a texel under 'zero'
+    flat(1, slice(128, 176), slice(16, 200), 0.999, 0.999)     # last texel: wraps / clamps / loses three taps
+    dy = rng.normal(size=(N, H, W, C)).astype(np.float32)
+    dy[0, 100:140, 10:70] = 0.0
+    kw = dict(filter_mode="linear-mipmap-linear", boundary_mode=bm)
+    g = oracle.texture_grad(tex, uv, dy, uv_da, None, **kw)
+
+    def run():
+        t_tex = _t(tex).requires_grad_(True)
+        t_uv = _t(uv).requires_grad_(True)
+        t_da = _t(uv_da).requires_grad_(True)
+        dr.texture(t_tex, t_uv, t_da, **kw).backward(_t(dy))
+        return t_tex.grad.cpu().numpy(), t_uv.grad.cpu().numpy(), t_da.grad.cpu().numpy()
+
+    lib = _plugin._capi.load()
+    assert lib.nvdr_texture_grad_scratch_bytes(N, H, W, C) == 4 * 11 * 13 * N * (8 + C) * 4
+    got = run()
+    within("two-level tex grad: g_tex", got[0], g["tex"], _tol(g["tex"]))
+    within("two-level tex grad: g_uv", got[1], g["uv"], _tol(g["uv"]))
+    within("two-level tex grad: g_uv_da", got[2], g["uv_da"], _tol(g["uv_da"]))
+    # the one-level path (no scratch): same results up to the order of the f32 sums
+    try:
+        _plugin._TEX_GRAD_SCRATCH = False
+        one = run()
+    finally:
+        _plugin._TEX_GRAD_SCRATCH = True
+    within("one-level tex grad: g_tex", one[0], g["tex"], _tol(g["tex"]))
+    assert np.array_equal(one[1], got[1]) and np.array_equal(one[2], got[2])
