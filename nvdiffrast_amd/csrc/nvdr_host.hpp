@@ -32,6 +32,9 @@ struct ProfileScope {
 //   64    k_fine timeline records pair counts instead of phase times (tools/fine_pairs.py)
 //   256   texture grad: no LDS patch table (direct global atomics)
 //   1024 / 2048  texture grad: skip slot lookups / table clear+flush (cost splits)
+//   16384 texture grad: ignore the caller's scratch (one-level reduction);  65536 / 131072  texture grad: no LDS adds /
+//         no slot lookups and no scatter at all (timing splits, tools/exp_tex_split.py)
+//   4194304 / 8388608  k_fine shared bins: arrival counter relaxed / release-only instead of acquire-release
 int debug_flags();
 // Optional device buffer for in-kernel timestamps (development only; nvdr_debug_buffer()).
 unsigned long long* debug_buffer();

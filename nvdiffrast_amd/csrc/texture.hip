@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     auto slots_of = [&](const Quad& q, int level, int* sl) {
         // The four taps of a bilinear footprint share patches most of the time: look each patch up once.
         sl[0] = sl[1] = sl[2] = sl[3] = -1;
-        if (direct || (p.dbg & 1024)) return;
+        if (direct || (p.dbg & (1024 | 131072))) return;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (q.tc[k] < 0 || q.tx[k] < 0) continue;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
             int lost = 0;                                        // sign bit: some valid tap (tc >= 0) of this lane has no slot (< 0)
 #pragma unroll
             for (int k = 0; k < 4; k++) lost |= (~q0.tc[k] & sl0[k]) | (second ? (~q1.tc[k] & sl1[k]) : 0);
-            const bool anyLost = __ballot(lost < 0) != 0ull;
+            const bool anyLost = !(p.dbg & 131072) && __ballot(lost < 0) != 0ull;     // (131072: timing experiment without lookups and scatter)
             for (int c = 0; c < C; c++) {
                 const float d = pDy[c];
                 const float d0 = kTri ? (1.f - flevel) * d : d;
@@ -890,7 +890,8 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
                     if (kTri) { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], v1[0], v1[1]); rs.scan3(v1[2], v1[3], z); }
                     else      { rs.scan3(v0[0], v0[1], v0[2]); rs.scan3(v0[3], z, z); }
                 }
-                if (rs.tail) {
+                if (p.dbg & 65536) {                                 // timing experiment: everything but the LDS adds
+                } else if (rs.tail) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) scatter(sl0[k], c, v0[k]);
                     if (second) {
@@ -976,12 +977,14 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
 }
 
 // Second level of the gradient reduction for constant-uv regions: merges the per-wave records of k_tex_grad (TexParams::rec)
-// and adds the totals to level 0 of the gradient texture.  One wave walks kFoldPerWave consecutive records, 64 at a time;
-// while the records it sees carry the same texel quad -- the rule: neighbouring waves of a background -- their
-// weight x total products are summed over the lanes (DPP) and kept in the last lane's registers, and only a change of
-// quad, or the end of the walk, costs 4 x C atomics.  Groups of 64 records with mixed quads (region borders) are added
-// record by record.  Order of the f32 sums: lanes in a DPP tree, then groups in sequence -- deterministic.
-constexpr int kFoldPerWave = 64 * 8;
+// and adds the totals to level 0 of the gradient texture.  One wave takes kFoldPerWave consecutive records, each lane
+// kFoldPerLane of them (strided by 64, so every load instruction is coalesced; all loads of a lane are independent and in
+// flight together).  A lane adds weight x total of the records that carry the same texel quad as its first one into
+// registers -- the rule: neighbouring waves of a background all do -- and sends the others (region borders) to memory one
+// by one; if then all lanes of the wave hold the same quad, their sums are combined over the lanes (DPP) and ONE lane
+// issues the 4 x C atomics, else every lane issues its own.  Order of the f32 sums: fixed by the launch geometry.
+constexpr int kFoldPerLane = 8;
+constexpr int kFoldPerWave = 64 * kFoldPerLane;
 
 template <int C_CT>
 __global__ __launch_bounds__(256) void k_tex_grad_fold(const int* __restrict__ rec, int nrec, int channels, float* __restrict__ gradTex)
@@ -990,71 +993,71 @@ __global__ __launch_bounds__(256) void k_tex_grad_fold(const int* __restrict__ r
     constexpr int CMAX = C_CT > 0 ? C_CT : 8;                 // generic instantiation: up to 8 channels in registers, more record by record
     const int lane = threadIdx.x & 63;
     const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    const int begin = wave * kFoldPerWave, end = min(begin + kFoldPerWave, nrec);
+    const int begin = wave * kFoldPerWave;
     if (begin >= nrec) return;
-    int run[4] = {-1, -1, -1, -1};                            // the quad being accumulated (valid in every lane: it is wave-uniform)
-    float acc[4][CMAX];                                       // its totals (lane 63)
+    const bool regs = C <= CMAX;
+    int mine[4] = {-1, -1, -1, -1};                           // this lane's quad (its first valid record's)
+    float acc[4][CMAX];
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
         for (int c = 0; c < CMAX; c++) acc[k][c] = 0.f;
-    auto flush = [&]() {
-        if (run[0] >= 0 && lane == 63) {
+    int t[kFoldPerLane][4];
+    float w[kFoldPerLane][4];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (run[k] >= 0)
-                    for (int c = 0; c < min(C, CMAX); c++)
-                        if (acc[k][c] != 0.f) atomic_add_f32(gradTex + (size_t)run[k] * C + c, acc[k][c]);
+    for (int i = 0; i < kFoldPerLane; i++) {
+        const int r = begin + i * 64 + lane;
+        const bool in = r < nrec;
+        t[i][0] = in ? rec[r] : -1;
+#pragma unroll
+        for (int k = 1; k < 4; k++) t[i][k] = in ? rec[(size_t)k * nrec + r] : -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[i][k] = in ? __int_as_float(rec[(size_t)(4 + k) * nrec + r]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < kFoldPerLane; i++) {
+        if (t[i][0] < 0) continue;                            // no record (the wave was not uniform) / no texel at all
+        const int r = begin + i * 64 + lane;
+        if (mine[0] < 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) mine[k] = t[i][k];
         }
+        const bool same = regs & (t[i][0] == mine[0]) & (t[i][1] == mine[1]) & (t[i][2] == mine[2]) & (t[i][3] == mine[3]);
+        for (int c = 0; c < C; c++) {
+            const float tot = __int_as_float(rec[(size_t)(kTexRecHeader + c) * nrec + r]);
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int c = 0; c < CMAX; c++) acc[k][c] = 0.f;
-    };
-    for (int r0 = begin; r0 < end; r0 += 64) {
-        const int r = r0 + lane;
-        int t[4] = {-1, -1, -1, -1};
-        if (r < end) {
-            t[0] = rec[r];
-            if (t[0] >= 0) { t[1] = rec[(size_t)nrec + r]; t[2] = rec[(size_t)2 * nrec + r]; t[3] = rec[(size_t)3 * nrec + r]; }
-        }
-        const bool valid = t[0] >= 0;
-        const uint64_t vm = __ballot(valid);
-        if (vm == 0ull) continue;
-        const int src = __builtin_ctzll(vm);
-        int f[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) f[k] = __builtin_amdgcn_readlane(t[k], src);
-        const bool same = !valid || ((t[0] == f[0]) & (t[1] == f[1]) & (t[2] == f[2]) & (t[3] == f[3]));
-        const bool uniform = (__ballot(same) == ~0ull) && C <= CMAX;
-        float w[4] = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) w[k] = __int_as_float(rec[(size_t)(4 + k) * nrec + r]);
-        }
-        if (uniform) {
-            if ((f[0] != run[0]) | (f[1] != run[1]) | (f[2] != run[2]) | (f[3] != run[3])) {
-                flush();
-#pragma unroll
-                for (int k = 0; k < 4; k++) run[k] = f[k];
-            }
-            for (int c = 0; c < min(C, CMAX); c++) {
-                const float tot = valid ? __int_as_float(rec[(size_t)(kTexRecHeader + c) * nrec + r]) : 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    acc[k][c] += wave_sum_to_last(w[k] * tot);                // valid in lane 63
-                }
-            }
-        } else if (valid) {
-            for (int c = 0; c < C; c++) {
-                const float tot = __int_as_float(rec[(size_t)(kTexRecHeader + c) * nrec + r]);
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (t[k] >= 0) atomic_add_f32(gradTex + (size_t)t[k] * C + c, w[k] * tot);
+            for (int k = 0; k < 4; k++) {
+                const float v = w[i][k] * tot;
+                if (same) { if (c < CMAX) acc[k][c < CMAX ? c : 0] += v; }
+                else if (t[i][k] >= 0) atomic_add_f32(gradTex + (size_t)t[i][k] * C + c, v);
             }
         }
     }
-    flush();
+    // combine over the lanes when the whole wave holds one quad (lanes without any record count as agreeing)
+    const bool have = mine[0] >= 0;
+    const uint64_t hm = __ballot(have);
+    if (hm == 0ull) return;
+    const int src = __builtin_ctzll(hm);
+    int f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = __builtin_amdgcn_readlane(mine[k], src);
+    const bool agree = !have || ((mine[0] == f[0]) & (mine[1] == f[1]) & (mine[2] == f[2]) & (mine[3] == f[3]));
+    if (__ballot(agree) == ~0ull) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) {
+                if (c >= C) continue;
+                const float sum = wave_sum_to_last(have ? acc[k][c] : 0.f);       // valid in lane 63
+                if (lane == 63 && f[k] >= 0 && sum != 0.f) atomic_add_f32(gradTex + (size_t)f[k] * C + c, sum);
+            }
+    } else if (have) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < CMAX; c++)
+                if (c < C && mine[k] >= 0 && acc[k][c] != 0.f) atomic_add_f32(gradTex + (size_t)mine[k] * C + c, acc[k][c]);
+    }
 }
 
 // ---- mip construction / mip gradient pull ------------------------------------------------------
