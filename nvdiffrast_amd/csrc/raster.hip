@@ -508,7 +508,7 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
                                                 int* __restrict__ poolCount, int* __restrict__ poolFinal, int* __restrict__ poolPeak, int N,
                                                 int4* __restrict__ order, int totalBins,
                                                 int* __restrict__ splitInfo, int4* __restrict__ helpers, int* __restrict__ splitDone,
-                                                int splitTris, int splitPart)
+                                                int splitTris, int splitPart, int* __restrict__ chunkNz, int binsX, int binsY)
 {
     __shared__ int s_bucket[32];
     __shared__ int4 s_split[kSplitsPerChunk];
@@ -527,6 +527,7 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int k = 0; k < 32; k++) { int c = s_bucket[k]; s_bucket[k] = acc; acc += c; }
+        chunkNz[blockIdx.x] = s_bucket[31];               // bins with triangles in this chunk: the empty ones follow them in the order
     }
     __syncthreads();
     for (int i = lo + threadIdx.x; i < hi; i += 1024) {
@@ -536,7 +537,12 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         const int hiSlot = binHi[i];
         const int scanLo = hiSlot ? ((0x7FFFFFFF - binLoInv[i]) & ~3) : 0;
         const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
-        order[lo + pos] = make_int4(i, c, scanLo, dlen);
+        int4 ent = make_int4(i, c, scanLo, dlen);
+        if (c == 0) {                                      // an empty bin: its coordinates, for the workgroup that clears it (k_fine)
+            const int n = i / (binsX * binsY), b = i - n * (binsX * binsY), by = b / binsX;
+            ent.z = (n << 10) | (by << 5) | (b - by * binsX);
+        }
+        order[lo + pos] = ent;
         // Bins with very many triangles (edge-on meshes) would each keep one workgroup busy for as long as the whole
         // launch takes: their slot range is shared by up to kSplitMaxParts workgroups (k_fine merges the parts' keys).
         // The kSplitsPerChunk heaviest bins of the chunk qualify: their position in the heavy-first order is their split number.
@@ -577,6 +583,7 @@ struct FineParams {
     const int4* order;
     const int* splitInfo; const int4* helpers;          // bins shared by several workgroups (k_order)
     unsigned long long* splitKeys; int* splitDone;      // their merged key arrays [split][64 tiles][64 px] and arrival counters
+    const int* chunkNz;                                 // per XCD chunk: bins with triangles (in the plain instantiation each also clears one empty bin)
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
@@ -600,6 +607,7 @@ struct FineShared {
     uint16_t queue[kFineWaves][kQueueSize];                // per-wave ring of surviving pairs: entry | tileX << 9 | tileY << 12
     int count;
     int totalPairs;
+    int ticket;                                            // rows of a partner bin handed to the waves as they finish (clear_bin)
 };
 
 // Rasterise up to 64 (triangle, tile) pairs, one pair per lane.
@@ -742,8 +750,38 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (info) { split = info >> 8; parts = info & 15; }
         }
     }
-    const int work = it4.x;
     const int binsPerImage = p.binsX * p.binsY;
+    // Zeros for every pixel of an empty bin (what the shader stores for a pixel without a triangle).  The parameters are
+    // read afresh from the kernarg segment through a pointer the compiler cannot see through: hoisted to the kernel's
+    // start they would occupy scalar registers across the raster stage, which has none to spare.
+    auto clear_bin = [](int packed, int wave) {                // packed = image << 10 | bin row << 5 | bin column (k_order)
+        const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const FineParams& q = *(const FineParams*)ka;
+        int lane;                                              // taken afresh (opaque): nothing of this stays live across the raster stage
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const int n2 = packed >> 10, by2 = (packed >> 5) & 31, bx2 = packed & 31;
+        const int Y = (by2 * kBinTiles + wave / kWavesPerRow) * 8 + (lane >> 3);
+        if (Y >= q.vp.vph) return;
+#pragma unroll 1
+        for (int tt = 0; tt < kTilesPerWave; tt++) {
+            const int X = (bx2 * kBinTiles + (wave % kWavesPerRow) * kTilesPerWave + tt) * 8 + (lane & 7);
+            if (X >= q.vp.vpw) continue;
+            const size_t pidx = ((size_t)n2 * q.H + (Y + q.vp.offy)) * q.W + (X + q.vp.offx);
+            ((float4*)q.out)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            store_streaming((float4*)q.out_db + pidx, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    };
+    // Empty bins are pure stores, and in the heavy-first order they all come last: 300 MB of zeros at the headline batch
+    // that nothing overlaps (the launch was store floor + the bins' compute).  In the plain instantiation each
+    // bin WITH triangles therefore also clears one empty bin of its chunk after shading its own -- the stores go out while
+    // other workgroups of the CU rasterise -- and the empty bin's own workgroup leaves at once.
+    constexpr bool kPlain = !PEEL && !WRITE_DEPTH && !DBG && !SPLIT;
+    const int work = it4.x;
+    if (kPlain && it4.y == 0) {
+        const int nz = p.chunkNz[xcd];
+        if (jj - nz < nz) return;                                          // cleared by the chunk's (jj - nz)-th bin
+    }                                                                      // (an empty bin without a partner takes the common path)
     const int n   = work / binsPerImage;
     const int bin = work - n * binsPerImage;
     const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
@@ -760,7 +798,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const unsigned long long kInit = ((unsigned long long)kDepthMax << 32) | 0xFFFFFFFFull;
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; t++) sh.key[wave / kWavesPerRow][(wave % kWavesPerRow) * kTilesPerWave + t][lane] = kInit;
-    if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
+    if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; sh.ticket = 0; }
     __syncthreads();
 
     // DBG experiment: bins at or above a triangle threshold (NVDR_DEBUG bits 20..31, x16) skip their raster stage
@@ -976,6 +1014,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         if (threadIdx.x == 0) {
             const int add = 1 + (landed >> 8);
             const int before = (p.dbg & 4194304) ? atomicAdd(&p.splitDone[split], add)
+                             : (p.dbg & 8388608) ? __hip_atomic_fetch_add(&p.splitDone[split], add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
                                                  : __hip_atomic_fetch_add(&p.splitDone[split], add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             sh.count = (before == parts - 1) ? 1 : 0;
         }
@@ -1047,6 +1086,22 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             // rast_db is write-once here and, in most op graphs, read late or never: a non-temporal store
             // keeps it from displacing `rast` (re-read by the next three kernels) in the Infinity Cache.
             store_streaming((float4*)p.out_db + pidx, odb);
+        }
+    }
+    if (kPlain) {
+        // (everything recomputed from the block index here: carrying the partner across the kernel cost spilled registers)
+        const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const FineParams& q = *(const FineParams*)ka;
+        const int perXcd2 = (q.totalBins + 7) >> 3;
+        const int xcd2 = (int)(blockIdx.x & 7), jj2 = (int)(blockIdx.x >> 3);
+        const int nz = q.chunkNz[xcd2], ne = min(perXcd2, q.totalBins - xcd2 * perXcd2) - nz;
+        if (jj2 < ne) {
+            // which tile row a wave clears is immaterial: rows are handed out as the waves arrive (the wave number itself is
+            // not kept in a register until here, and recomputing it would keep the thread id alive across the kernel)
+            int row = 0;
+            if (laneS == 0) row = atomicAdd(&sh.ticket, 1);
+            clear_bin(__builtin_amdgcn_readfirstlane(q.order[xcd2 * perXcd2 + nz + jj2].z), __builtin_amdgcn_readfirstlane(row));
         }
     }
     if (DBG && p.dbgbuf && lane == 0 && item >= 0) {
@@ -1368,7 +1423,8 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         {
             ProfileScope ps("raster_order", stream);
             hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, poolPeak, N, order, totalBins,
-                               (int*)(sb + L.splitInfo), (int4*)(sb + L.helpers), (int*)(sb + L.splitDone), splitTris, splitPart);
+                               (int*)(sb + L.splitInfo), (int4*)(sb + L.helpers), (int*)(sb + L.splitDone), splitTris, splitPart,
+                               (int*)(sb + L.poolPeak + 16), binsX, binsY);
         }
         NVDR_LAUNCH_CHECK();
 
@@ -1380,6 +1436,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.order = order;
         fp.splitInfo = (const int*)(sb + L.splitInfo); fp.helpers = (const int4*)(sb + L.helpers);
         fp.splitKeys = (unsigned long long*)(sb + L.splitKeys); fp.splitDone = (int*)(sb + L.splitDone);
+        fp.chunkNz = (const int*)(sb + L.poolPeak + 16);                                        // 8 ints behind the pool-demand counter
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
