@@ -94,18 +94,22 @@ size_t nvdr_rasterize_pool_peak_offset(int N, int max_tri, int H, int W, long lo
  * [N,Hpad,Wpad] u32 or NULL (NULL = no peel test, i.e. peeling_idx <= 0).  depth_out:
  * [N,Hpad,Wpad] u32 or NULL (only a DepthPeeler needs it).  Hpad/Wpad = H/W rounded up
  * to 8.  out, out_db: [N,H,W,4] f32. */
+/* tile_flags (optional output, NULL = none): [N][ceil(H/8)][ceil(W/8)] bytes, 1 = some pixel of that 8x8-pixel tile of
+ * `out` shows a triangle, 0 = the whole tile is background.  The entry points below that READ a rast tensor take the
+ * same array as an optional input (`tile_flags`, NULL = none) and then skip the rast / rast_db bytes of empty tiles --
+ * legal only while that rast tensor is exactly what this call wrote (the operator layer checks identity and version). */
 int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
                        int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                        const uint32_t* peel_depth, uint32_t* depth_out,
                        void* scratch, size_t scratch_bytes, int scratch_clean, long long pool_per_image,
-                       float* out, float* out_db, nvdrStream_t stream);
+                       float* out, float* out_db, uint8_t* tile_flags, nvdrStream_t stream);
 
 /* grad_pos (shape of pos) must be zero-filled by the caller (reference: zeros_like,
  * torch_rasterize.cpp:237).  ddb == NULL selects the rasterize_grad variant. */
 int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,
                         const float* dy, const float* ddb,
                         int instance_mode, int N, int V, int T, int H, int W,
-                        float* grad_pos, nvdrStream_t stream);
+                        float* grad_pos, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* ---- interpolate ----------------------------------------------------------------
  * Replaces interpolate_fwd / interpolate_fwd_da / interpolate_grad / interpolate_grad_da
@@ -119,7 +123,7 @@ int nvdr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tr
                          const float* rast_db, int attr_instance, int attr_n,
                          int N, int V, int A, int T, int H, int W,
                          int diff_all, const int32_t* diff_attrs_host, int num_diff,
-                         float* out, float* out_da, nvdrStream_t stream);
+                         float* out, float* out_da, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* g_attr (shape of attr) must be zero-filled by the caller (torch_interpolate.cpp:211);
  * g_rast [N,H,W,4] and g_rast_db [N,H,W,4] (NULL without differentials) are fully written. */
@@ -128,7 +132,7 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
                           int attr_instance, int attr_n,
                           int N, int V, int A, int T, int H, int W,
                           int diff_all, const int32_t* diff_attrs_host, int num_diff,
-                          float* g_attr, float* g_rast, float* g_rast_db, nvdrStream_t stream);
+                          float* g_attr, float* g_rast, float* g_rast_db, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* ---- interpolate + rasterize backward in one pass --------------------------------------
  * Not an entry point of the reference: the work of interpolate_grad (torch_interpolate.cpp:242-248; interpolate.cu:131-274)
@@ -143,7 +147,7 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
 int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const int32_t* tri, const float* pos,
                                     const float* dy, int attr_instance, int attr_n, int pos_instance,
                                     int N, int V, int A, int T, int H, int W,
-                                    float* g_attr, float* g_pos, float* g_rast, nvdrStream_t stream);
+                                    float* g_attr, float* g_pos, float* g_rast, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* ---- texture --------------------------------------------------------------------
  * Replaces texture_construct_mip / texture_fwd / texture_fwd_mip / texture_grad_nearest /
@@ -208,7 +212,7 @@ int nvdr_antialias_construct_topology_hash(const int32_t* tri, int T, void* hash
 int nvdr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
                        const void* hash, size_t hash_bytes,
                        int instance_mode, int N, int V, int T, int H, int W, int C,
-                       float* out, void* work, size_t work_bytes, nvdrStream_t stream);
+                       float* out, void* work, size_t work_bytes, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* g_color [N,H,W,C] is fully written (copy of dy + corrections); g_pos (shape of pos) must be
  * zero-filled by the caller (torch_antialias.cpp:219). */

@@ -17,7 +17,7 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
-ABI_VERSION = 5            # include/nvdr_hip.h; 2: scratch_clean; 3: options + log; 4: caller-chosen clip pool; 5: fused backward
+ABI_VERSION = 6            # include/nvdr_hip.h; 2: scratch_clean; 3: options + log; 4: caller-chosen clip pool; 5: fused backward, texture_grad scratch; 6: tile flags
 OPT_LOG_LEVEL, OPT_CUBE_CORNER_FIX, OPT_SCRATCH_LIMIT_MB = 0, 1, 2
 c_longlong = ctypes.c_longlong
 
@@ -34,17 +34,17 @@ SIGNATURES = {
     "nvdr_rasterize_scratch_bytes_pool": (c_size_t, [c_int, c_int, c_int, c_int, c_longlong]),
     "nvdr_rasterize_pool_peak_offset": (c_size_t, [c_int, c_int, c_int, c_int, c_longlong]),
     "nvdr_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_longlong, c_void_p, c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nvdr_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nvdr_interpolate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p]),
+                                     c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nvdr_interpolate_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_int, c_int,
-                                      c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nvdr_interpolate_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nvdr_texture_mip_info": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _intp, _intp, _i64p, _i64p]),
     "nvdr_texture_construct_mip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nvdr_texture_fwd": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p,
@@ -57,7 +57,7 @@ SIGNATURES = {
     "nvdr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nvdr_antialias_construct_topology_hash": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "nvdr_antialias_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "nvdr_antialias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }

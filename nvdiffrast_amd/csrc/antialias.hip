@@ -30,6 +30,7 @@ struct AAParams {
     unsigned hashMask;
     int numTriangles, numVertices, width, height, n, channels, instance;
     float xh, yh;
+    TileFlags flags;                                        // which 8x8 tiles of rast show a triangle at all, or f == nullptr
 };
 
 __device__ __forceinline__ bool same_sign(float a, float b) { return (__float_as_int(a) ^ __float_as_int(b)) >= 0; }
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p, int 
             const int py = row0 + r;
             if (py >= p.height) break;
             const size_t pidx = (size_t)px + (size_t)p.width * (py + (size_t)p.height * pz);
+            // no triangle in this pixel's tile nor in its right / lower neighbour's: three equal ids, nothing to read
+            if (p.flags.f && p.flags.empty(pz, py, px) && (px + 1 >= p.width || p.flags.empty(pz, py, px + 1))
+                && (py + 1 >= p.height || p.flags.empty(pz, py + 1, px))) continue;
             const float tri0 = p.rast[pidx * 4 + 3];         // compared as floats, like the reference
             if (px < p.width - 1 && p.rast[(pidx + 1) * 4 + 3] != tri0) { c1 |= 1u << r; cnt++; }
             if (py < p.height - 1 && p.rast[(pidx + p.width) * 4 + 3] != tri0) { c2 |= 1u << r; cnt++; }
@@ -473,12 +477,13 @@ extern "C" int nvdr_antialias_construct_topology_hash(const int32_t* tri, int T,
 extern "C" int nvdr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
                                   const void* hash, size_t hash_bytes,
                                   int instance_mode, int N, int V, int T, int H, int W, int C,
-                                  float* out, void* work, size_t work_bytes, nvdrStream_t stream_)
+                                  float* out, void* work, size_t work_bytes, const uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     AAParams p;
     int rc = fill_aa(p, "antialias_fwd", color, rast, pos, tri, instance_mode, N, V, T, H, W, C);
     if (rc) return rc;
+    p.flags = TileFlags{(debug_flags() & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
     NVDR_REQUIRE(hash && out && work, "antialias_fwd: null pointer");
     NVDR_REQUIRE(!((uintptr_t)work & 15), "work_buffer internal tensor not aligned to int4");
     NVDR_REQUIRE(!((uintptr_t)hash & 15), "topology_hash internal tensor not aligned to int4");

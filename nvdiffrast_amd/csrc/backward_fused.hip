@@ -30,6 +30,7 @@ struct FusedParams {
     int width, height, depth;
     int attrBC, attrInstance, posInstance, dbg;
     float xs, xo, ys, yo;
+    TileFlags flags;                                        // which 8x8 tiles of rast show a triangle at all, or f == nullptr
 };
 
 constexpr int kFuBlockW = 64;
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(kFuThreads, 8) void k_interp_raster_grad(const Fuse
         for (int k = 0; k < 9; k++) g[r][k] = 0.f;          // the run scan multiplies masked lanes by 0: keep them finite
         if (py >= p.height || px >= p.width) continue;
         const size_t pidx = ((size_t)pz * p.height + py) * p.width + px;
-        const float4 rr = ((const float4*)p.rast)[pidx];
+        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.flags.empty(pz, py, px)) rr = ((const float4*)p.rast)[pidx];     // (an empty tile's rast is not read)
         const int triIdx = float_to_triidx(rr.w) - 1;
         if (triIdx < 0 || triIdx >= p.numTriangles) {
             if (WRITE_GRAST) ((float4*)p.gradRaster)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -230,7 +232,7 @@ static size_t fused_lds_bytes(int slots, int A) { return (size_t)slots * (8 * (s
 extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const int32_t* tri, const float* pos,
                                                const float* dy, int attr_instance, int attr_n, int pos_instance,
                                                int N, int V, int A, int T, int H, int W,
-                                               float* g_attr, float* g_pos, float* g_rast, nvdrStream_t stream_)
+                                               float* g_attr, float* g_pos, float* g_rast, const uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched
@@ -251,6 +253,7 @@ extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* r
     p.attrBC = (attr_instance && attr_n == 1) ? 1 : 0;
     p.posInstance = pos_instance ? 1 : 0;
     p.dbg = debug_flags();
+    p.flags = TileFlags{(p.dbg & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
     p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
     p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
     const int gx = (W + kFuBlockW - 1) / kFuBlockW, gy = (H + kFuBlockH - 1) / kFuBlockH;

@@ -80,6 +80,19 @@ __device__ __forceinline__ float4 load_streaming(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// ---- tile occupancy of a rasterized image ---------------------------------------------
+// k_fine notes for every 8x8-pixel tile whether ANY of its pixels shows a triangle (one byte per tile, [N][ceil(H/8)]
+// [ceil(W/8)]).  The kernels that consume `rast` -- interpolate forward / backward, rasterize backward, the antialias
+// discontinuity pass -- get the flags from the operator layer when the rast they are given is, untouched, the tensor that
+// rasterize() returned (ops.py `_RasterOrigin`), and then do not read the 16 (32) bytes per pixel of rast (rast_db) of an
+// empty tile at all: two thirds of the tiles of the benchmark scene.  f == nullptr: no information, read everything.
+struct TileFlags {
+    const uint8_t* f; int w, h;
+    __device__ __forceinline__ bool empty(int pz, int py, int px) const {
+        return f != nullptr && f[((size_t)pz * h + (py >> 3)) * w + (px >> 3)] == 0;
+    }
+};
+
 // ---- triangle-id <-> f32 codec (reference csrc/common/common.h:186-193) ----------
 // Identity up to 2^24; above that the id is stored as a bit-offset float so that it
 // survives the f32 channel.

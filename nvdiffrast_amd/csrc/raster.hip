@@ -584,6 +584,7 @@ struct FineParams {
     const int* splitInfo; const int4* helpers;          // bins shared by several workgroups (k_order)
     unsigned long long* splitKeys; int* splitDone;      // their merged key arrays [split][64 tiles][64 px] and arrival counters
     const int* chunkNz;                                 // per XCD chunk: bins with triangles (in the plain instantiation each also clears one empty bin)
+    uint8_t* tileFlags; int tfW, tfH;                   // out, optional: per 8x8 tile of the image, 1 = some pixel shows a triangle (nvdr_device.hpp TileFlags)
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
@@ -770,6 +771,8 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             const size_t pidx = ((size_t)n2 * q.H + (Y + q.vp.offy)) * q.W + (X + q.vp.offx);
             ((float4*)q.out)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
             store_streaming((float4*)q.out_db + pidx, make_float4(0.f, 0.f, 0.f, 0.f));
+            if (q.tileFlags && lane == 0)                      // (lane 0 = the tile's first pixel: inside the viewport here)
+                q.tileFlags[((size_t)n2 * q.tfH + ((Y + q.vp.offy) >> 3)) * q.tfW + ((X + q.vp.offx) >> 3)] = 0;
         }
     };
     // Empty bins are pure stores, and in the heavy-first order they all come last: 300 MB of zeros at the headline batch
@@ -1037,6 +1040,13 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (X < vpwPad && Y < vphPad)
                 p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
         }
+        if (p.tileFlags) {
+            // tile occupancy for the consumers of rast (TileFlags): does any pixel of this tile, inside the viewport, show a triangle?
+            const bool hit = (X < p.vp.vpw) & (Y < p.vp.vph) & ((uint32_t)key != 0xFFFFFFFFu);
+            const uint64_t any = __ballot(hit);
+            if (laneS == 0 && X < p.vp.vpw && Y < p.vp.vph)    // lane 0 = the tile's first pixel
+                p.tileFlags[((size_t)n * p.tfH + ((Y + p.vp.offy) >> 3)) * p.tfW + ((X + p.vp.offx) >> 3)] = any ? 1 : 0;
+        }
         if (X >= p.vp.vpw || Y >= p.vp.vph) continue;
         const int px = X + p.vp.offx, py = Y + p.vp.offy;
         const size_t pidx = ((size_t)n * p.H + py) * p.W + px;
@@ -1117,6 +1127,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 struct GradParams {
     const float* pos; const int* tri; const float* out; const float* dy; const float* ddb;
     float* grad;
+    TileFlags flags;
     int instance, N, V, T, W, H;
     float xs, xo, ys, yo;
     int dbg;
@@ -1143,6 +1154,7 @@ template <bool ENABLE_DB>
 __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const float4* __restrict__ vb, int px, int py, int pz, PixelGrad& r)
 {
     if (px >= p.W) return false;
+    if (p.flags.empty(pz, py, px)) return false;                      // nothing visible in this 8x8 tile: rast is not read
     const size_t pidx = ((size_t)pz * p.H + py) * p.W + px;
     const int triIdx = float_to_triidx(p.out[pidx * 4 + 3]) - 1;
     if (triIdx < 0 || triIdx >= p.T) return false;
@@ -1345,7 +1357,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
                                   int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                                   const uint32_t* peel_depth, uint32_t* depth_out,
                                   void* scratch, size_t scratch_bytes, int scratch_clean, long long pool_per_image,
-                                  float* out, float* out_db, nvdrStream_t stream_)
+                                  float* out, float* out_db, uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
@@ -1437,6 +1449,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.splitInfo = (const int*)(sb + L.splitInfo); fp.helpers = (const int4*)(sb + L.helpers);
         fp.splitKeys = (unsigned long long*)(sb + L.splitKeys); fp.splitDone = (int*)(sb + L.splitDone);
         fp.chunkNz = (const int*)(sb + L.poolPeak + 16);                                        // 8 ints behind the pool-demand counter
+        fp.tileFlags = tile_flags; fp.tfW = (W + 7) >> 3; fp.tfH = (H + 7) >> 3;
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
@@ -1464,7 +1477,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
 extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,
                                    const float* dy, const float* ddb,
                                    int instance_mode, int N, int V, int T, int H, int W,
-                                   float* grad_pos, nvdrStream_t stream_)
+                                   float* grad_pos, const uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
@@ -1477,6 +1490,7 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
     NVDR_REQUIRE(!((uintptr_t)out & 15), "out tensor not aligned to float4");
     GradParams p;
     p.pos = pos; p.tri = tri; p.out = out; p.dy = dy; p.ddb = ddb; p.grad = grad_pos;
+    p.flags = TileFlags{(debug_flags() & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
     p.instance = instance_mode ? 1 : 0; p.N = N; p.V = V; p.T = T; p.W = W; p.H = H;
     p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
     p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;

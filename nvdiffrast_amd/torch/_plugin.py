@@ -171,6 +171,7 @@ class RasterizeCRStateWrapper:
         self.reported_bytes = 0
         self.pools = {}          # (N, max_tri) -> clip-pool slots per image that the last call in growing mode needed
         self.sizes = {}          # (N, max_tri, H, W, pool) -> scratch bytes
+        self.last_flags = None   # tile occupancy of the most recent rasterize_fwd_cuda output (ops.py attaches it to that rast)
         self.depth = None        # current depth surface  [N,Hp,Wp] int32 (u32 bits)
         self.peel = None         # previous layer's depth surface
 
@@ -269,6 +270,8 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     with _on_device(dev):
         out = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         out_db = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
+        # one byte per 8x8 tile: does any pixel show a triangle?  Consumers of `out` skip the empty tiles (include/nvdr_hip.h)
+        flags = torch.empty((depth, (height + 7) >> 3, (width + 7) >> 3), dtype=torch.uint8, device=dev)
         # Depth surfaces exist only while peeling (peeling_idx >= 0); layer k > 0 reads layer k-1's.
         peel_in = depth_out = None
         if peeling_idx >= 0:
@@ -293,7 +296,7 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
                                         int(instance_mode), depth, V, T, max_tri, height, width,
                                         _capi.ptr(peel_in), _capi.ptr(depth_out),
                                         scratch.data_ptr(), scratch.numel(), int(clean), pool,
-                                        out.data_ptr(), out_db.data_ptr(), _stream(dev))
+                                        out.data_ptr(), out_db.data_ptr(), flags.data_ptr(), _stream(dev))
             if rc != 0 or not adaptive or pool < 0 or pool >= worst_pool:
                 break                                                        # (worst-case pool: nothing to read back)
             off = lib.nvdr_rasterize_pool_peak_offset(depth, max_tri, height, width, pool)
@@ -307,10 +310,21 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
             _log_info("Clip pool grown to %d sub-triangle slots per image" % pool)
     _capi.check(rc, fn)
     state.mark_clean(layout)
+    state.last_flags = flags
     return out, out_db
 
 
-def rasterize_grad_db(pos, tri, out, dy, ddb):
+def _flags_ok(fn, tile_flags, n, h, w, dev):
+    """tile_flags (not a reference argument): None, or the uint8 [N, ceil(H/8), ceil(W/8)] tensor rasterize_fwd_cuda made for
+    exactly the rast tensor being passed."""
+    if tile_flags is None:
+        return None
+    _require(tile_flags.dtype == torch.uint8 and tile_flags.is_contiguous() and tile_flags.device == dev
+             and tuple(tile_flags.shape) == (n, (h + 7) >> 3, (w + 7) >> 3), fn, "tile_flags do not belong to this rast tensor")
+    return tile_flags.data_ptr()
+
+
+def rasterize_grad_db(pos, tri, out, dy, ddb, tile_flags=None):
     """torch_rasterize.cpp:171-256.  ``ddb`` may be None (== rasterize_grad)."""
     fn = "rasterize_grad_db"
     enable_db = ddb is not None
@@ -346,14 +360,15 @@ def rasterize_grad_db(pos, tri, out, dy, ddb):
         grad = torch.zeros_like(pos)
         rc = _capi.load().nvdr_rasterize_grad(pos.data_ptr(), tri.data_ptr(), out.data_ptr(), dy_.data_ptr(),
                                               _capi.ptr(ddb_), int(instance_mode), depth, V, tri.size(0),
-                                              height, width, grad.data_ptr(), _stream(dev))
+                                              height, width, grad.data_ptr(), _flags_ok(fn, tile_flags, depth, height, width, dev),
+                                              _stream(dev))
     _capi.check(rc, fn)
     return grad
 
 
-def rasterize_grad(pos, tri, out, dy):
+def rasterize_grad(pos, tri, out, dy, tile_flags=None):
     """torch_rasterize.cpp:259-263."""
-    return rasterize_grad_db(pos, tri, out, dy, None)
+    return rasterize_grad_db(pos, tri, out, dy, None, tile_flags)
 
 
 # ----------------------------------------------------------------------------- interpolate
@@ -368,7 +383,7 @@ def _diff_list(diff_attrs_vec):
     return arr, n
 
 
-def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec):
+def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec, tile_flags=None):
     """torch_interpolate.cpp:42-124."""
     fn = "interpolate_fwd_da"
     enable_da = (rast_db is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
@@ -413,17 +428,18 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec)
                                                int(instance_mode), attr.size(0) if instance_mode else 1,
                                                N, V, A, tri.size(0), H, W,
                                                int(bool(diff_attrs_all)), lst, nlst,
-                                               out.data_ptr(), out_da.data_ptr() if enable_da else None, _stream(dev))
+                                               out.data_ptr(), out_da.data_ptr() if enable_da else None,
+                                               _flags_ok(fn, tile_flags, N, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
     return out, out_da
 
 
-def interpolate_fwd(attr, rast, tri):
+def interpolate_fwd(attr, rast, tri, tile_flags=None):
     """torch_interpolate.cpp:127-132."""
-    return interpolate_fwd_da(attr, rast, tri, None, False, [])
+    return interpolate_fwd_da(attr, rast, tri, None, False, [], tile_flags)
 
 
-def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_attrs_vec):
+def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_attrs_vec, tile_flags=None):
     """torch_interpolate.cpp:137-239."""
     fn = "interpolate_grad_da"
     enable_da = (rast_db is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
@@ -476,18 +492,19 @@ def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_
                                                 rast_db.data_ptr() if enable_da else None, _capi.ptr(dda_),
                                                 int(instance_mode), attr_depth, N, V, A, tri.size(0), H, W,
                                                 int(bool(diff_attrs_all)), lst, nlst,
-                                                g_attr.data_ptr(), g_rast.data_ptr(), _capi.ptr(g_rast_db), _stream(dev))
+                                                g_attr.data_ptr(), g_rast.data_ptr(), _capi.ptr(g_rast_db),
+                                                _flags_ok(fn, tile_flags, N, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
     return g_attr, g_rast, g_rast_db
 
 
-def interpolate_grad(attr, rast, tri, dy):
+def interpolate_grad(attr, rast, tri, dy, tile_flags=None):
     """torch_interpolate.cpp:242-248."""
-    g_attr, g_rast, _ = interpolate_grad_da(attr, rast, tri, dy, None, None, False, [])
+    g_attr, g_rast, _ = interpolate_grad_da(attr, rast, tri, dy, None, None, False, [], tile_flags)
     return g_attr, g_rast
 
 
-def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True):
+def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_flags=None):
     """Not in the reference's module: interpolate_grad (torch_interpolate.cpp:242-248) and rasterize_grad
     (torch_rasterize.cpp:259-263) of the graph rasterize -> interpolate in ONE kernel (csrc/backward_fused.hip).
     -> (g_attr, g_rast or None, g_pos), equal to
@@ -524,7 +541,8 @@ def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True):
         g_rast = torch.empty_like(rast) if with_g_rast else None
         rc = _capi.load().nvdr_interpolate_rasterize_grad(attr.data_ptr(), rast.data_ptr(), tri.data_ptr(), pos.data_ptr(), dy_.data_ptr(),
                                                           int(attr_instance), attr_depth, int(pos_instance), N, V, A, tri.size(0), H, W,
-                                                          g_attr.data_ptr(), g_pos.data_ptr(), _capi.ptr(g_rast), _stream(dev))
+                                                          g_attr.data_ptr(), g_pos.data_ptr(), _capi.ptr(g_rast),
+                                                          _flags_ok(fn, tile_flags, N, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
     return g_attr, g_rast, g_pos
 
@@ -828,7 +846,7 @@ def _aa_checks(fn, color, rast, pos, tri, dy=None):
     return instance_mode
 
 
-def antialias_fwd(color, rast, pos, tri, topology_hash_wrap):
+def antialias_fwd(color, rast, pos, tri, topology_hash_wrap, tile_flags=None):
     """torch_antialias.cpp:68-155 -> (out, work_buffer)."""
     fn = "antialias_fwd"
     topology_hash = topology_hash_wrap.ev_hash
@@ -846,7 +864,8 @@ def antialias_fwd(color, rast, pos, tri, topology_hash_wrap):
         rc = lib.nvdr_antialias_fwd(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(),
                                     topology_hash.data_ptr(), topology_hash.numel() * 4,
                                     int(instance_mode), N, V, tri.size(0), H, W, C,
-                                    out.data_ptr(), work_buffer.data_ptr(), work_buffer.numel() * 4, _stream(dev))
+                                    out.data_ptr(), work_buffer.data_ptr(), work_buffer.numel() * 4,
+                                    _flags_ok(fn, tile_flags, N, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
     return out, work_buffer
 

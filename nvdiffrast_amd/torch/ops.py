@@ -116,20 +116,28 @@ class _RasterOrigin:
     gradient in one pass, returns g_rast as usual -- always a correct gradient -- and leaves the position gradient here;
     rasterize's backward takes it when the tensor it receives is that g_rast, and otherwise computes the gradient from
     what it did receive, as if nothing had been prepared (the context then stops preparing: `fused_disabled`)."""
-    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "interpolations", "pending")
+    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "interpolations", "pending", "flags")
 
-    def __init__(self, pos, tri, state, rast):
+    def __init__(self, pos, tri, state, rast, flags):
         self.pos, self.tri, self.state = pos, tri, state
         self.rast_ptr, self.rast_version = rast.data_ptr(), rast._version
         self.interpolations = 0            # interpolate() calls that took this rast
         self.pending = None                # (g_rast, its data_ptr, its version, g_pos) between the two backward nodes
+        self.flags = flags                 # tile occupancy of this rast (one byte per 8x8 tile), written by the rasterizer
+
+    def flags_for(self, rast):
+        """The occupancy flags, if `rast` still is what rasterize() returned (same storage, never written to since):
+        the kernels that read rast then skip the tiles without any triangle (include/nvdr_hip.h `tile_flags`)."""
+        if rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version:
+            return self.flags
+        return None
 
     def usable_by(self, attr, rast, tri):
         """interpolate(attr, rast, tri) may prepare the position gradient: this very rast, untouched, the same triangle
         tensor (pose-style scripts interpolate with another index buffer), one vertex set, nobody else doing the same."""
         st = self.state
         return (_plugin.fused_backward_mode() == "auto" and not st.fused_disabled and self.pending is None
-                and self.interpolations == 1 and rast.requires_grad
+                and self.interpolations == 1 and rast.requires_grad and self.pos.requires_grad
                 and rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version
                 and tri.data_ptr() == self.tri.data_ptr() and tri.shape == self.tri.shape
                 and attr.shape[-2] == self.pos.shape[-2])
@@ -142,9 +150,7 @@ class _RasterizeOp:
     def forward(raster_ctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
         state = raster_ctx.cpp_wrapper
         rast, rast_db = _plugin.rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx)
-        origin = None
-        if pos.requires_grad and not state.fused_disabled:
-            origin = rast._nvdr_origin = _RasterOrigin(pos, tri, state, rast)
+        origin = rast._nvdr_origin = _RasterOrigin(pos, tri, state, rast, state.last_flags)
         return (rast, rast_db), (pos, tri, rast), (bool(grad_db), origin)
 
     @staticmethod
@@ -165,10 +171,11 @@ class _RasterizeOp:
             if not grad_db:
                 return (None,) * 7
             d_rast = torch.zeros_like(rast)
+        flags = origin.flags_for(rast)
         if grad_db and d_rast_db is not None:
-            g_pos = _plugin.rasterize_grad_db(pos, tri, rast, d_rast, d_rast_db)
+            g_pos = _plugin.rasterize_grad_db(pos, tri, rast, d_rast, d_rast_db, tile_flags=flags)
         else:
-            g_pos = _plugin.rasterize_grad(pos, tri, rast, d_rast)
+            g_pos = _plugin.rasterize_grad(pos, tri, rast, d_rast, tile_flags=flags)
         return None, g_pos, None, None, None, None, None
 
 
@@ -178,13 +185,14 @@ class _InterpolateOp:
     @staticmethod
     def forward(attr, rast, tri, rast_db, diff_all, diff_list):
         with_da = rast_db is not None
+        origin = getattr(rast, "_nvdr_origin", None)     # set by rasterize() on its own output (fused backward, tile flags)
+        flags = None if origin is None else origin.flags_for(rast)
         if with_da:
-            outs = _plugin.interpolate_fwd_da(attr, rast, tri, rast_db, diff_all, diff_list)
+            outs = _plugin.interpolate_fwd_da(attr, rast, tri, rast_db, diff_all, diff_list, tile_flags=flags)
             keep = (attr, rast, tri, rast_db)
         else:
-            outs = _plugin.interpolate_fwd(attr, rast, tri)
+            outs = _plugin.interpolate_fwd(attr, rast, tri, tile_flags=flags)
             keep = (attr, rast, tri)
-        origin = getattr(rast, "_nvdr_origin", None)     # set by rasterize() on its own output (fused backward)
         if origin is not None:
             origin.interpolations += 1
         return tuple(outs), keep, (with_da, diff_all, diff_list, origin)
@@ -193,11 +201,12 @@ class _InterpolateOp:
     def _plain_grad(attr, rast, tri, d_out, origin):
         """Gradient without pixel differentials; with the position gradient prepared in the same pass when the rast
         came straight from rasterize() and this is its only interpolation (see _RasterOrigin)."""
+        flags = None if origin is None else origin.flags_for(rast)
         if origin is not None and origin.usable_by(attr, rast, tri):
-            g_attr, g_rast, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out)
+            g_attr, g_rast, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, tile_flags=flags)
             origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos)
             return g_attr, g_rast
-        return _plugin.interpolate_grad(attr, rast, tri, d_out)
+        return _plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)
 
     @staticmethod
     def backward(state, saved, d_out, d_out_da):
@@ -210,7 +219,8 @@ class _InterpolateOp:
             return g_attr, g_rast, None, None, None, None
         if with_da:
             attr, rast, tri, rast_db = saved
-            g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list)
+            g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
+                                                                    tile_flags=None if origin is None else origin.flags_for(rast))
             return g_attr, g_rast, None, g_rast_db, None, None
         attr, rast, tri = saved
         g_attr, g_rast = _InterpolateOp._plain_grad(attr, rast, tri, d_out, origin)
@@ -268,7 +278,9 @@ class _AntialiasOp:
 
     @staticmethod
     def forward(color, rast, pos, tri, topology_hash, pos_gradient_boost):
-        out, work_buffer = _plugin.antialias_fwd(color, rast, pos, tri, topology_hash)
+        origin = getattr(rast, "_nvdr_origin", None)
+        out, work_buffer = _plugin.antialias_fwd(color, rast, pos, tri, topology_hash,
+                                                 tile_flags=None if origin is None else origin.flags_for(rast))
         return out, (color, rast, pos, tri), (pos_gradient_boost, work_buffer)
 
     @staticmethod

@@ -51,10 +51,10 @@ def test_scratch_query_is_pure_host_code(lib):
 
 def test_bad_arguments_are_rejected_before_any_launch(lib):
     # Null pointers / empty shapes must come back as NVDR_ERR_ARG with a message, not crash.
-    rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, 0, -1, None, None, None)
+    rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, 0, -1, None, None, None, None)
     assert rc == 1
     assert b"null pointer" in lib.nvdr_last_error()
-    rc = lib.nvdr_interpolate_fwd(None, None, None, None, 1, 1, 1, 3, 4, 1, 8, 8, 0, None, 0, None, None, None)
+    rc = lib.nvdr_interpolate_fwd(None, None, None, None, 1, 1, 1, 3, 4, 1, 8, 8, 0, None, 0, None, None, None, None)
     assert rc == 1
 
 
@@ -77,7 +77,7 @@ def test_texture_and_antialias_host_side(lib):
     assert rc == 1 and b"null pointer" in lib.nvdr_last_error()
     rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 7, 1, None, None)
     assert rc == 1 and b"filter_mode unsupported" in lib.nvdr_last_error()
-    rc = lib.nvdr_antialias_fwd(None, None, None, None, None, 0, 1, 1, 3, 1, 4, 4, 3, None, None, 0, None)
+    rc = lib.nvdr_antialias_fwd(None, None, None, None, None, 0, 1, 1, 3, 1, 4, 4, 3, None, None, 0, None, None)
     assert rc == 1 and b"null pointer" in lib.nvdr_last_error()
 
 

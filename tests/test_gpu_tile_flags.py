@@ -1,0 +1,109 @@
+"""Tile occupancy flags (include/nvdr_hip.h `tile_flags`; nvdr_device.hpp TileFlags): the rasterizer notes per 8x8 tile
+whether any pixel shows a triangle, and the kernels that read rast skip the empty tiles -- only while the rast tensor is,
+untouched, the one rasterize() returned."""
+import numpy as np
+import pytest
+import torch
+from conftest import ATOL, grad_tol, within
+
+from nvdiffrast_amd.utils import m10k_batch, stress_triangles
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _expected_flags(rast):
+    """max over each 8x8 tile of (id > 0), from the rast tensor itself."""
+    occ = (rast[..., 3] > 0)
+    n, h, w = occ.shape
+    hp, wp = (h + 7) // 8 * 8, (w + 7) // 8 * 8
+    pad = torch.zeros((n, hp, wp), dtype=torch.bool, device=occ.device)
+    pad[:, :h, :w] = occ
+    return pad.view(n, hp // 8, 8, wp // 8, 8).any(4).any(2).to(torch.uint8)
+
+
+@pytest.mark.parametrize("res,n,kind", [((512, 512), 3, "mesh"), ((100, 77), 2, "mesh"), ((8, 2056), 1, "mesh"), ((2100, 300), 1, "mesh"),
+                                        ((256, 256), 2, "soup"), ((64, 64), 40, "mesh"), ((520, 1030), 2, "strip")])
+def test_flags_describe_the_rast_tensor(dr, res, n, kind):
+    """Every in-image tile is written exactly once -- by the bin's own workgroup, by the workgroup that clears an empty bin
+    for it, by the last part of a shared bin -- and says whether the tile shows a triangle (incl. >2048 px tiled viewports,
+    sizes that are not multiples of 8 or 64, and the depth-peeling instantiations)."""
+    if kind == "soup":
+        b = stress_triangles(n, T=400, res=res[0], seed=5)
+        pos, tri = b["pos"], b["tri"]
+    else:
+        b = m10k_batch(n, seed=50 + n, nx=30, ny=16)
+        pos, tri = b["pos"].copy(), b["tri"]
+        if kind == "strip":
+            pos[..., 0] *= 0.05                                   # thousands of triangles per bin: shared bins in a small launch
+    ctx = dr.RasterizeCudaContext()
+    t_pos, t_tri = _t(pos), _t(tri)
+    rast, _ = dr.rasterize(ctx, t_pos, t_tri, res)
+    flags = ctx.cpp_wrapper.last_flags
+    assert flags.dtype == torch.uint8 and tuple(flags.shape) == (n, (res[0] + 7) // 8, (res[1] + 7) // 8)
+    want = _expected_flags(rast)
+    assert torch.equal(flags, want), int((flags != want).sum())
+    assert 0 < int(want.sum()) < want.numel()                     # both kinds of tile occur
+    assert rast._nvdr_origin.flags_for(rast) is flags
+    with dr.DepthPeeler(ctx, t_pos, t_tri, res) as peeler:
+        for _ in range(2):
+            r, _ = peeler.rasterize_next_layer()
+            assert torch.equal(ctx.cpp_wrapper.last_flags, _expected_flags(r))
+
+
+def test_consumers_skip_empty_tiles_only_for_the_untouched_rast(dr, oracle):
+    """interpolate / antialias / the backward kernels through the operator layer (flags attached) against the oracle, and the
+    same after an in-place edit of rast: the version counter moved, the flags are dropped, and the kernels read the edited
+    tensor -- a triangle painted into a tile that the flags call empty must show up."""
+    from nvdiffrast_amd import _capi
+    from nvdiffrast_amd.torch import _plugin
+    N, res = 2, (128, 192)
+    b = m10k_batch(N, seed=61, nx=20, ny=10)
+    pos_np = b["pos"].copy(); pos_np[..., :2] *= 0.6                         # plenty of empty tiles around the mesh
+    rng = np.random.default_rng(6)
+    G = rng.normal(size=(N,) + res + (4,)).astype(np.float32)
+    tri = _t(b["tri"])
+    ctx = dr.RasterizeCudaContext()
+    pos = _t(pos_np).requires_grad_(True)
+    attr = _t(b["attr"]).requires_grad_(True)
+    rast, rast_db = dr.rasterize(ctx, pos, tri, res)
+    flags = rast._nvdr_origin.flags_for(rast)
+    assert flags is not None and int((flags == 0).sum()) > flags.numel() // 4
+    out, out_da = dr.interpolate(attr, rast, tri, rast_db=rast_db, diff_attrs="all")
+    col = torch.rand((N,) + res + (3,), device="cuda")
+    aa = dr.antialias(col, rast, pos, tri)
+    ((out * _t(G)).sum() + (out_da ** 2).sum() + (aa * aa).sum()).backward()
+    ro, rdbo = oracle.rasterize(pos_np, b["tri"], res)
+    oo, odao = oracle.interpolate(b["attr"], ro, b["tri"], rdbo, "all")
+    within("flags: interpolate", out.detach().cpu().numpy(), oo, ATOL)
+    within("flags: interpolate da", out_da.detach().cpu().numpy(), odao, grad_tol(odao))
+    aao = oracle.antialias(col.cpu().numpy(), ro, pos_np, b["tri"])
+    within("flags: antialias", aa.detach().cpu().numpy(), aao, ATOL)
+    ga, gr, grdb = oracle.interpolate_grad(b["attr"], ro, b["tri"], G, rdbo, 2 * odao, "all")
+    _gc, gpa = oracle.antialias_grad(col.cpu().numpy(), ro, pos_np, b["tri"], 2 * aao)
+    gp = oracle.rasterize_grad(pos_np, b["tri"], ro, gr, grdb) + gpa
+    within("flags: g_attr", attr.grad.cpu().numpy(), ga, grad_tol(ga))
+    within("flags: g_pos", pos.grad.cpu().numpy(), gp, grad_tol(gp, 2))
+
+    # the same kernels with and without the flags give identical bits where no atomics are involved
+    a = _plugin.interpolate_fwd(attr.detach(), rast.detach(), tri, tile_flags=flags)[0]
+    bb = _plugin.interpolate_fwd(attr.detach(), rast.detach(), tri)[0]
+    assert torch.equal(a, bb)
+
+    # an in-place edit: a triangle id painted into an empty tile
+    empty = torch.nonzero(flags[0] == 0)[0]
+    ty, tx = int(empty[0]), int(empty[1])
+    r2, _ = dr.rasterize(ctx, _t(pos_np), tri, res)
+    assert r2._nvdr_origin.flags_for(r2) is not None
+    with torch.no_grad():
+        r2[0, ty * 8 + 3, tx * 8 + 2] = torch.tensor([0.25, 0.5, 0.0, 7.0], device="cuda")
+    assert r2._nvdr_origin.flags_for(r2) is None                             # version counter moved
+    o2, _ = dr.interpolate(attr.detach(), r2, tri)
+    want, _ = oracle.interpolate(b["attr"], r2.cpu().numpy(), b["tri"])
+    assert np.abs(want[0, ty * 8 + 3, tx * 8 + 2]).max() > 0
+    within("edited rast: interpolate", o2.cpu().numpy(), want, ATOL)
+    # a copy of rast has no flags either (nothing is assumed about tensors the rasterizer did not hand out itself)
+    assert getattr(rast.detach().clone(), "_nvdr_origin", None) is None
