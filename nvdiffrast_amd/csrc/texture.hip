@@ -991,10 +991,15 @@ __global__ __launch_bounds__(256) void k_tex_grad_fold(const int* __restrict__ r
 {
     const int C = C_CT > 0 ? C_CT : channels;
     constexpr int CMAX = C_CT > 0 ? C_CT : 8;                 // generic instantiation: up to 8 channels in registers, more record by record
+    // third level, inside the workgroup: waves that end up with the same quad hand their sums to wave 0 through LDS, so a
+    // background costs 4 x C atomics per 2048 records (same-address f32 atomics execute one after another at the memory
+    // side: with one set per wave they were the whole run time of this kernel)
+    __shared__ int s_quad[4][4];
+    __shared__ float s_sum[4][4][CMAX];
     const int lane = threadIdx.x & 63;
-    const int wave = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int wid = (int)(threadIdx.x >> 6);
+    const int wave = (int)blockIdx.x * 4 + wid;
     const int begin = wave * kFoldPerWave;
-    if (begin >= nrec) return;
     const bool regs = C <= CMAX;
     int mine[4] = {-1, -1, -1, -1};                           // this lane's quad (its first valid record's)
     float acc[4][CMAX];
@@ -1036,20 +1041,23 @@ __global__ __launch_bounds__(256) void k_tex_grad_fold(const int* __restrict__ r
     // combine over the lanes when the whole wave holds one quad (lanes without any record count as agreeing)
     const bool have = mine[0] >= 0;
     const uint64_t hm = __ballot(have);
-    if (hm == 0ull) return;
-    const int src = __builtin_ctzll(hm);
+    const int src = hm ? __builtin_ctzll(hm) : 0;
     int f[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) f[k] = __builtin_amdgcn_readlane(mine[k], src);
+    for (int k = 0; k < 4; k++) f[k] = hm ? __builtin_amdgcn_readlane(mine[k], src) : -1;
     const bool agree = !have || ((mine[0] == f[0]) & (mine[1] == f[1]) & (mine[2] == f[2]) & (mine[3] == f[3]));
-    if (__ballot(agree) == ~0ull) {
+    const bool waveUniform = hm != 0ull && __ballot(agree) == ~0ull;
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_quad[wid][k] = waveUniform ? f[k] : -2;        // -2: nothing to hand over
+    }
+    if (waveUniform) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
             for (int c = 0; c < CMAX; c++) {
-                if (c >= C) continue;
-                const float sum = wave_sum_to_last(have ? acc[k][c] : 0.f);       // valid in lane 63
-                if (lane == 63 && f[k] >= 0 && sum != 0.f) atomic_add_f32(gradTex + (size_t)f[k] * C + c, sum);
+                const float sum = wave_sum_to_last((have && c < C) ? acc[k][c] : 0.f);       // valid in lane 63
+                if (lane == 63) s_sum[wid][k][c] = sum;
             }
     } else if (have) {
 #pragma unroll
@@ -1057,6 +1065,26 @@ __global__ __launch_bounds__(256) void k_tex_grad_fold(const int* __restrict__ r
 #pragma unroll
             for (int c = 0; c < CMAX; c++)
                 if (c < C && mine[k] >= 0 && acc[k][c] != 0.f) atomic_add_f32(gradTex + (size_t)mine[k] * C + c, acc[k][c]);
+    }
+    __syncthreads();
+    // wave 0: one lane per (tap, channel); a wave's sums join those of the first wave with the same quad
+    if (wid == 0 && lane < 4 * CMAX) {
+        const int k = lane / CMAX, c = lane - k * CMAX;
+        bool done[4] = {false, false, false, false};
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (done[a] || s_quad[a][0] == -2) continue;
+            float sum = s_sum[a][k][c];
+#pragma unroll
+            for (int b = a + 1; b < 4; b++) {
+                if (!done[b] && s_quad[b][0] == s_quad[a][0] && s_quad[b][1] == s_quad[a][1] && s_quad[b][2] == s_quad[a][2] && s_quad[b][3] == s_quad[a][3]) {
+                    sum += s_sum[b][k][c];
+                    done[b] = true;
+                }
+            }
+            const int texel = s_quad[a][k];
+            if (c < C && texel >= 0 && sum != 0.f) atomic_add_f32(gradTex + (size_t)texel * C + c, sum);
+        }
     }
 }
 
