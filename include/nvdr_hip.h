@@ -143,11 +143,17 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
  *   g_rast [N,H,W,4] = what interpolate_grad would have written, or NULL to skip it (only legal when nothing else
  *   consumes the gradient of `rast`; the operator layer always asks for it, see nvdiffrast_amd/torch/ops.py).
  * attr_instance / attr_n as for nvdr_interpolate_grad; pos_instance != 0: pos [N,V,4], else pos [V,4] (range mode).
- * Results equal those of the two separate calls up to the summation order of the f32 atomics. */
+ * Results equal those of the two separate calls up to the summation order of the f32 atomics.
+ * With pixel differentials (rast_db and dda given, diff_all / diff_attrs_host / num_diff as for nvdr_interpolate_grad) it is
+ * interpolate_grad_da followed by rasterize_grad_db; g_rast_db [N,H,W,4] is written next to g_rast; db_to_pos == 0 keeps
+ * the gradient of rast_db away from pos (a rasterize call made with grad_db = False). */
 int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const int32_t* tri, const float* pos,
                                     const float* dy, int attr_instance, int attr_n, int pos_instance,
                                     int N, int V, int A, int T, int H, int W,
-                                    float* g_attr, float* g_pos, float* g_rast, const uint8_t* tile_flags, nvdrStream_t stream);
+                                    const float* rast_db, const float* dda,
+                                    int diff_all, const int32_t* diff_attrs_host, int num_diff, int db_to_pos,
+                                    float* g_attr, float* g_pos, float* g_rast, float* g_rast_db,
+                                    const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* ---- texture --------------------------------------------------------------------
  * Replaces texture_construct_mip / texture_fwd / texture_fwd_mip / texture_grad_nearest /

@@ -44,7 +44,9 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_int, _i32p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nvdr_interpolate_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                                c_int, c_int, c_int, c_int, c_int, c_int,
+                                                c_void_p, c_void_p, c_int, _i32p, c_int, c_int,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nvdr_texture_mip_info": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _intp, _intp, _i64p, _i64p]),
     "nvdr_texture_construct_mip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nvdr_texture_fwd": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p,

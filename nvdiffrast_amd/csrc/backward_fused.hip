@@ -23,9 +23,16 @@
 
 namespace nvdr {
 
+constexpr int kFuMaxDiffAttrs = 32;                      // interpolate.h:18 IP_MAX_DIFF_ATTRS
+
 struct FusedParams {
     const int* tri; const float* attr; const float* rast; const float* pos; const float* dy;
     float* gradAttr; float* gradPos; float* gradRaster;
+    // pixel differentials (interpolate_grad_da + rasterize_grad_db): rast_db, upstream gradient of the attribute
+    // differentials, gradient of rast_db (written like g_rast), the differentiated attributes
+    const float* rastDB; const float* dda; float* gradRasterDB;
+    int numDiffAttr, diffAll, dbToPos;                      // dbToPos: the rasterize call propagates rast_db's gradient (grad_db)
+    int diffAttrs[kFuMaxDiffAttrs];
     int numTriangles, numVertices, numAttr;
     int width, height, depth;
     int attrBC, attrInstance, posInstance, dbg;
@@ -39,8 +46,17 @@ constexpr int kFuWaves = 8;
 constexpr int kFuThreads = kFuWaves * 64;
 constexpr int kFuRows = kFuBlockH / kFuWaves;          // rows per wave
 
-template <int A_CT, bool WRITE_GRAST>
-__global__ __launch_bounds__(kFuThreads, 8) void k_interp_raster_grad(const FusedParams p, int slots, int gx, int gy)
+__device__ __forceinline__ int fused_diff_index(const FusedParams& p, int i)
+{
+    int j = p.diffAll ? i : p.diffAttrs[i];
+    if (j < 0) j += p.numAttr;                              // python-style (interpolate.cu:102-103)
+    return (j >= 0 && j < p.numAttr) ? j : -1;
+}
+
+// ENABLE_DA: the variant with pixel differentials -- interpolate_grad_da (interpolate.cu:233-269) feeding
+// rasterize_grad_db (rasterize.cu:214-267): config 3's backward pair.
+template <int A_CT, bool WRITE_GRAST, bool ENABLE_DA>
+__global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster_grad(const FusedParams p, int slots, int gx, int gy)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     constexpr bool kRegs = (A_CT == 4 || A_CT == 2);        // upstream gradient stays in registers between the phases
@@ -88,7 +104,10 @@ __global__ __launch_bounds__(kFuThreads, 8) void k_interp_raster_grad(const Fuse
         if (!p.flags.empty(pz, py, px)) rr = ((const float4*)p.rast)[pidx];     // (an empty tile's rast is not read)
         const int triIdx = float_to_triidx(rr.w) - 1;
         if (triIdx < 0 || triIdx >= p.numTriangles) {
-            if (WRITE_GRAST) ((float4*)p.gradRaster)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WRITE_GRAST) {
+                ((float4*)p.gradRaster)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ENABLE_DA) ((float4*)p.gradRasterDB)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             continue;
         }
         const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
@@ -129,12 +148,32 @@ __global__ __launch_bounds__(kFuThreads, 8) void k_interp_raster_grad(const Fuse
         if (WRITE_GRAST) ((float4*)p.gradRaster)[pidx] = make_float4(gb0, gb1, 0.f, 0.f);
         mA = max_abs_keep_nan(mA, ymax * bmax);             // >= every |b_k * dy_i| (rounding is monotone)
 
-        // rasterize backward of this pixel with (gb0, gb1) as the upstream gradient of (u, v); pixels whose upstream
-        // gradient is all +-0 contribute nothing (rasterize.cu:143-148)
-        if ((((uint32_t)(__float_as_int(gb0) | __float_as_int(gb1))) << 1) != 0u) {
+        float4 gdb = make_float4(0.f, 0.f, 0.f, 0.f);       // gradient of rast_db = (du/dX, du/dY, dv/dX, dv/dY)
+        if (ENABLE_DA) {
+            const float4 db = ((const float4*)p.rastDB)[pidx];
+            const float2* dda = ((const float2*)p.dda) + pidx * p.numDiffAttr;
+            for (int i = 0; i < p.numDiffAttr; i++) {
+                const int j = fused_diff_index(p, i);
+                if (j < 0) continue;
+                const float2 d = dda[i];
+                const float dsdu = a0[j] - a2[j], dsdv = a1[j] - a2[j];
+                gdb.x += dsdu * d.x; gdb.y += dsdu * d.y;
+                gdb.z += dsdv * d.x; gdb.w += dsdv * d.y;
+                const float du = d.x * db.x + d.y * db.y;
+                const float dv = d.x * db.z + d.y * db.w;
+                mA = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(mA, du), dv), -du - dv);
+            }
+            if (WRITE_GRAST) ((float4*)p.gradRasterDB)[pidx] = gdb;
+            if (!p.dbToPos) gdb = make_float4(0.f, 0.f, 0.f, 0.f);       // rasterize(..., grad_db=False): not propagated to pos
+        }
+
+        // rasterize backward of this pixel with (gb0, gb1) [and gdb] as the upstream gradient of (u, v) [and their pixel
+        // differentials]; pixels whose upstream gradient is all +-0 contribute nothing (rasterize.cu:143-148)
+        const int nz_db = ENABLE_DA ? (__float_as_int(gdb.x) | __float_as_int(gdb.y) | __float_as_int(gdb.z) | __float_as_int(gdb.w)) : 0;
+        if ((((uint32_t)(__float_as_int(gb0) | __float_as_int(gb1) | nz_db)) << 1) != 0u) {
             const float fx = p.xs * (float)px + p.xo;
             const float fy = p.ys * (float)py + p.yo;
-            raster_tape<false>(P, fx, fy, p.xs, p.ys, gb0, gb1, make_float4(0.f, 0.f, 0.f, 0.f), false, g[r]);
+            raster_tape<ENABLE_DA>(P, fx, fy, p.xs, p.ys, gb0, gb1, gdb, ENABLE_DA && (((uint32_t)nz_db) << 1) != 0u, g[r]);
 #pragma unroll
             for (int k = 0; k < 9; k++) mP = max_abs_keep_nan(mP, g[r][k]);
         }
@@ -189,6 +228,23 @@ __global__ __launch_bounds__(kFuThreads, 8) void k_interp_raster_grad(const Fuse
             if (!direct) rs.scan3(v0, v1, v2);
             put3(i, v0, v1, v2);
         }
+        if (ENABLE_DA) {
+            // attribute gradients through the pixel differentials: du, dv, -(du + dv) to the three vertices' attribute j
+            float4 db = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[r]) db = ((const float4*)p.rastDB)[pidx];
+            const float2* dda = ((const float2*)p.dda) + pidx * p.numDiffAttr;
+            for (int i = 0; i < p.numDiffAttr; i++) {
+                const int j = fused_diff_index(p, i);
+                if (j < 0) continue;
+                float2 d = make_float2(0.f, 0.f);
+                if (ok[r]) d = dda[i];
+                float du = d.x * db.x + d.y * db.y;
+                float dv = d.x * db.z + d.y * db.w;
+                float dw = -du - dv;
+                if (!direct) rs.scan3(du, dv, dw);
+                put3(j, du, dv, dw);
+            }
+        }
         // position components (x, y, w) of vertex k
         if (maxP != 0u) {
 #pragma unroll
@@ -232,7 +288,10 @@ static size_t fused_lds_bytes(int slots, int A) { return (size_t)slots * (8 * (s
 extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const int32_t* tri, const float* pos,
                                                const float* dy, int attr_instance, int attr_n, int pos_instance,
                                                int N, int V, int A, int T, int H, int W,
-                                               float* g_attr, float* g_pos, float* g_rast, const uint8_t* tile_flags, nvdrStream_t stream_)
+                                               const float* rast_db, const float* dda,
+                                               int diff_all, const int32_t* diff_attrs_host, int num_diff, int db_to_pos,
+                                               float* g_attr, float* g_pos, float* g_rast, float* g_rast_db,
+                                               const uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched
@@ -244,9 +303,24 @@ extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* r
     NVDR_REQUIRE(!((uintptr_t)rast & 15), "rast input tensor not aligned to float4");
     NVDR_REQUIRE(!((uintptr_t)pos & 15), "pos input tensor not aligned to float4");
     NVDR_REQUIRE(!((uintptr_t)g_rast & 15), "grad_rast output tensor not aligned to float4");
+    const bool enable_da = rast_db && dda && (diff_all || num_diff > 0);
+    NVDR_REQUIRE(!enable_da || !g_rast || g_rast_db, "interpolate_rasterize_grad: g_rast_db missing");
+    NVDR_REQUIRE(!((uintptr_t)rast_db & 15), "rast_db input tensor not aligned to float4");
+    NVDR_REQUIRE(!((uintptr_t)dda & 7), "dda input tensor not aligned to float2");
+    NVDR_REQUIRE(!((uintptr_t)g_rast_db & 15), "grad_rast_db output tensor not aligned to float4");
     FusedParams p{};
     p.tri = tri; p.attr = attr; p.rast = rast; p.pos = pos; p.dy = dy;
     p.gradAttr = g_attr; p.gradPos = g_pos; p.gradRaster = g_rast;
+    if (enable_da) {
+        p.rastDB = rast_db; p.dda = dda; p.gradRasterDB = g_rast_db; p.dbToPos = db_to_pos ? 1 : 0;
+        if (diff_all) { p.numDiffAttr = A; p.diffAll = 1; }
+        else {
+            NVDR_REQUIRE(num_diff <= kFuMaxDiffAttrs, "too many entries in diff_attrs list (increase IP_MAX_DIFF_ATTRS)");
+            NVDR_REQUIRE(diff_attrs_host, "interpolate_rasterize_grad: diff_attrs list missing");
+            p.numDiffAttr = num_diff;
+            for (int i = 0; i < num_diff; i++) p.diffAttrs[i] = diff_attrs_host[i];
+        }
+    }
     p.numTriangles = T; p.numVertices = V; p.numAttr = A;
     p.width = W; p.height = H; p.depth = N;
     p.attrInstance = attr_instance ? 1 : 0;
@@ -269,13 +343,14 @@ extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* r
     const bool vec4 = (A == 4) && !((uintptr_t)attr & 15) && !((uintptr_t)dy & 15);
     const bool vec2 = (A == 2) && !((uintptr_t)attr & 7) && !((uintptr_t)dy & 7);
     {
-        ProfileScope ps("interp_raster_grad", stream);
-#define NVDR_FUSED(ACT)                                                                                                    \
-    do {                                                                                                                    \
-        if (g_rast) hipLaunchKernelGGL((k_interp_raster_grad<ACT, true>),  grid, block, lds, stream, p, slots, gx, gy);    \
-        else        hipLaunchKernelGGL((k_interp_raster_grad<ACT, false>), grid, block, lds, stream, p, slots, gx, gy);    \
+        ProfileScope ps(enable_da ? "interp_raster_grad_da" : "interp_raster_grad", stream);
+#define NVDR_FUSED(ACT, DA)                                                                                                      \
+    do {                                                                                                                          \
+        if (g_rast) hipLaunchKernelGGL((k_interp_raster_grad<ACT, true, DA>),  grid, block, lds, stream, p, slots, gx, gy);      \
+        else        hipLaunchKernelGGL((k_interp_raster_grad<ACT, false, DA>), grid, block, lds, stream, p, slots, gx, gy);      \
     } while (0)
-        if (vec4) NVDR_FUSED(4); else if (vec2) NVDR_FUSED(2); else NVDR_FUSED(0);
+        if (enable_da) { if (vec4) NVDR_FUSED(4, true); else if (vec2) NVDR_FUSED(2, true); else NVDR_FUSED(0, true); }
+        else           { if (vec4) NVDR_FUSED(4, false); else if (vec2) NVDR_FUSED(2, false); else NVDR_FUSED(0, false); }
     }
     NVDR_LAUNCH_CHECK();
     return NVDR_OK;

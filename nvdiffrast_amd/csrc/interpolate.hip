@@ -24,6 +24,7 @@ struct InterpParams {
     int attrBC, instance_mode, diff_attrs_all, dbg;
     int streamOut;          // forward: the output is too large to stay in the Infinity Cache anyway -> non-temporal stores
     int widthShift;         // log2(width) when the width is a power of two, else -1 (forward: pixel row without a division)
+    int daVec4;             // forward: A = 2 with diff_attrs = 'all' and a 16-byte aligned out_da: one float4 store per pixel
     TileFlags flags;        // which 8x8 tiles of rast show a triangle at all (nvdr_device.hpp), or f == nullptr
     int diffAttrs[kMaxDiffAttrs];
 };
@@ -68,12 +69,17 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
     float* out = p.out + pidx * A;
     float2* outDA = ENABLE_DA ? ((float2*)p.outDA) + pidx * p.numDiffAttr : nullptr;
 
+    // The usual texture-coordinate case -- two attributes, both differentiated -- writes its four differentials as one
+    // 16-byte store (two 8-byte stores at a 16-byte stride reach memory as partial lines) and takes the attribute
+    // differences from the rows that are already in registers.
+    const bool da4 = ENABLE_DA && A_CT == 2 && p.daVec4;
     if (!valid) {
         // No triangle: zeros (the reference reaches the same values via zero barycentrics, :73-80).
         if (A_CT == 4)      { if (p.streamOut) store_streaming((float4*)out, make_float4(0.f, 0.f, 0.f, 0.f)); else *(float4*)out = make_float4(0.f, 0.f, 0.f, 0.f); }
         else if (A_CT == 2) *(float2*)out = make_float2(0.f, 0.f);
         else for (int i = 0; i < A; i++) out[i] = 0.f;
-        if (ENABLE_DA) for (int i = 0; i < p.numDiffAttr; i++) outDA[i] = make_float2(0.f, 0.f);
+        if (da4) *(float4*)outDA = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (ENABLE_DA) for (int i = 0; i < p.numDiffAttr; i++) outDA[i] = make_float2(0.f, 0.f);
         return;
     }
     if (p.instance_mode && !p.attrBC) { vi0 += pz * p.numVertices; vi1 += pz * p.numVertices; vi2 += pz * p.numVertices; }
@@ -90,6 +96,12 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
     } else if (A_CT == 2) {
         float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
         *(float2*)out = make_float2(b0 * x0.x + b1 * x1.x + b2 * x2.x, b0 * x0.y + b1 * x1.y + b2 * x2.y);
+        if (da4) {
+            const float4 db = ((const float4*)p.rastDB)[pidx];
+            const float du0 = x0.x - x2.x, dv0 = x1.x - x2.x, du1 = x0.y - x2.y, dv1 = x1.y - x2.y;
+            *(float4*)outDA = make_float4(db.x * du0 + db.z * dv0, db.y * du0 + db.w * dv0, db.x * du1 + db.z * dv1, db.y * du1 + db.w * dv1);
+            return;
+        }
     } else {
         for (int i = 0; i < A; i++) out[i] = b0 * a0[i] + b1 * a1[i] + b2 * a2[i];
     }
@@ -376,6 +388,7 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
     NVDR_REQUIRE(!enable_da || out_da, "interpolate_fwd: out_da missing");
     NVDR_REQUIRE(!((uintptr_t)out_da & 7), "out_da output tensor not aligned to float2");
     p.out = out; p.outDA = enable_da ? out_da : nullptr;
+    p.daVec4 = (enable_da && A == 2 && diff_all && !((uintptr_t)out_da & 15)) ? 1 : 0;
     // An output larger than most of the 256 MB Infinity Cache cannot be found there by its consumer anyway; written
     // around the cache it leaves `rast` (read again by the backward kernels) in place.
     p.streamOut = ((size_t)N * H * W * A * sizeof(float) > ((size_t)192 << 20)) ? 1 : 0;

@@ -504,17 +504,26 @@ def interpolate_grad(attr, rast, tri, dy, tile_flags=None):
     return g_attr, g_rast
 
 
-def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_flags=None):
-    """Not in the reference's module: interpolate_grad (torch_interpolate.cpp:242-248) and rasterize_grad
-    (torch_rasterize.cpp:259-263) of the graph rasterize -> interpolate in ONE kernel (csrc/backward_fused.hip).
-    -> (g_attr, g_rast or None, g_pos), equal to
-        g_attr, g_rast = interpolate_grad(attr, rast, tri, dy);  g_pos = rasterize_grad(pos, tri, rast, g_rast)
-    up to the summation order of the atomics.  `with_g_rast=False` skips writing g_rast (only legal when nothing else
-    consumes the gradient of rast).  attr and pos must index the same vertices with the same `tri`."""
+def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_flags=None,
+                               rast_db=None, dda=None, diff_attrs_all=False, diff_attrs_vec=(), db_to_pos=True):
+    """Not in the reference's module: interpolate_grad[_da] (torch_interpolate.cpp:137-248) and rasterize_grad[_db]
+    (torch_rasterize.cpp:171-263) of the graph rasterize -> interpolate in ONE kernel (csrc/backward_fused.hip).
+    -> (g_attr, g_rast or None, g_rast_db or None, g_pos), equal to
+        g_attr, g_rast[, g_rast_db] = interpolate_grad[_da](attr, rast, tri, dy[, rast_db, dda, ...])
+        g_pos = rasterize_grad[_db](pos, tri, rast, g_rast[, g_rast_db])
+    up to the summation order of the atomics.  `with_g_rast=False` skips writing g_rast / g_rast_db (only legal when nothing
+    else consumes the gradient of rast).  `db_to_pos=False`: rast_db's gradient is not propagated to pos (grad_db=False).
+    attr and pos must index the same vertices with the same `tri`."""
     fn = "interpolate_rasterize_grad"
-    dev = _check_device(fn, attr=attr, rast=rast, tri=tri, pos=pos, dy=dy)
-    _check_contiguous(fn, attr=attr, rast=rast, tri=tri, pos=pos)
-    _check_f32(fn, attr=attr, rast=rast, pos=pos, dy=dy)
+    enable_da = (rast_db is not None) and (dda is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
+    if enable_da:
+        dev = _check_device(fn, attr=attr, rast=rast, tri=tri, pos=pos, dy=dy, rast_db=rast_db, dda=dda)
+        _check_contiguous(fn, attr=attr, rast=rast, tri=tri, pos=pos, rast_db=rast_db)
+        _check_f32(fn, attr=attr, rast=rast, pos=pos, dy=dy, rast_db=rast_db, dda=dda)
+    else:
+        dev = _check_device(fn, attr=attr, rast=rast, tri=tri, pos=pos, dy=dy)
+        _check_contiguous(fn, attr=attr, rast=rast, tri=tri, pos=pos)
+        _check_f32(fn, attr=attr, rast=rast, pos=pos, dy=dy)
     _check_i32(fn, tri=tri)
     attr_instance = attr.dim() > 2
     pos_instance = pos.dim() > 2
@@ -534,17 +543,29 @@ def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_
     _require(V == pos.size(1 if pos_instance else 0), fn, "attr and pos must have the same number of vertices")
     _require(dy.dim() == 4 and tuple(dy.shape) == (N, H, W, A), fn, "dy must have shape [depth, height, width, attributes]")
     _require(attr_depth == N or attr_depth == 1, fn, "minibatch size mismatch between inputs rast, dy, attr")
+    D = 0
+    if enable_da:
+        D = A if diff_attrs_all else len(diff_attrs_vec)
+        _require(tuple(rast_db.shape) == (N, H, W, 4), fn, "rast_db must have shape[>0, >0, >0, 4]")
+        _require(dda.dim() == 4 and tuple(dda.shape) == (N, H, W, 2 * D), fn, "dda must have shape [>0, height, width, ?]")
+        if not diff_attrs_all:
+            _require(len(diff_attrs_vec) <= _IP_MAX_DIFF_ATTRS, fn, "too many entries in diff_attrs list (increase IP_MAX_DIFF_ATTRS)")
     dy_ = dy.contiguous()
+    dda_ = dda.contiguous() if enable_da else None
+    lst, nlst = _diff_list([] if (diff_attrs_all or not enable_da) else diff_attrs_vec)
     with _on_device(dev):
         g_attr = torch.zeros_like(attr)
         g_pos = torch.zeros_like(pos)
         g_rast = torch.empty_like(rast) if with_g_rast else None
+        g_rast_db = torch.empty_like(rast_db) if (with_g_rast and enable_da) else None
         rc = _capi.load().nvdr_interpolate_rasterize_grad(attr.data_ptr(), rast.data_ptr(), tri.data_ptr(), pos.data_ptr(), dy_.data_ptr(),
                                                           int(attr_instance), attr_depth, int(pos_instance), N, V, A, tri.size(0), H, W,
-                                                          g_attr.data_ptr(), g_pos.data_ptr(), _capi.ptr(g_rast),
+                                                          rast_db.data_ptr() if enable_da else None, _capi.ptr(dda_),
+                                                          int(bool(diff_attrs_all)), lst, nlst, int(bool(db_to_pos)),
+                                                          g_attr.data_ptr(), g_pos.data_ptr(), _capi.ptr(g_rast), _capi.ptr(g_rast_db),
                                                           _flags_ok(fn, tile_flags, N, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
-    return g_attr, g_rast, g_pos
+    return g_attr, g_rast, g_rast_db, g_pos
 
 
 # ----------------------------------------------------------------------------- texture

@@ -116,11 +116,13 @@ class _RasterOrigin:
     gradient in one pass, returns g_rast as usual -- always a correct gradient -- and leaves the position gradient here;
     rasterize's backward takes it when the tensor it receives is that g_rast, and otherwise computes the gradient from
     what it did receive, as if nothing had been prepared (the context then stops preparing: `fused_disabled`)."""
-    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "interpolations", "pending", "flags")
+    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "db_ptr", "db_version", "grad_db",
+                 "interpolations", "pending", "flags")
 
-    def __init__(self, pos, tri, state, rast, flags):
+    def __init__(self, pos, tri, state, rast, flags, rast_db, grad_db):
         self.pos, self.tri, self.state = pos, tri, state
         self.rast_ptr, self.rast_version = rast.data_ptr(), rast._version
+        self.db_ptr, self.db_version, self.grad_db = rast_db.data_ptr(), rast_db._version, bool(grad_db)
         self.interpolations = 0            # interpolate() calls that took this rast
         self.pending = None                # (g_rast, its data_ptr, its version, g_pos) between the two backward nodes
         self.flags = flags                 # tile occupancy of this rast (one byte per 8x8 tile), written by the rasterizer
@@ -132,13 +134,15 @@ class _RasterOrigin:
             return self.flags
         return None
 
-    def usable_by(self, attr, rast, tri):
-        """interpolate(attr, rast, tri) may prepare the position gradient: this very rast, untouched, the same triangle
-        tensor (pose-style scripts interpolate with another index buffer), one vertex set, nobody else doing the same."""
+    def usable_by(self, attr, rast, tri, rast_db=None):
+        """interpolate(attr, rast, tri[, rast_db]) may prepare the position gradient: this very rast (and rast_db),
+        untouched, the same triangle tensor (pose-style scripts interpolate with another index buffer), one vertex set,
+        nobody else doing the same."""
         st = self.state
         return (_plugin.fused_backward_mode() == "auto" and not st.fused_disabled and self.pending is None
                 and self.interpolations == 1 and rast.requires_grad and self.pos.requires_grad
                 and rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version
+                and (rast_db is None or (rast_db.data_ptr() == self.db_ptr and rast_db._version == self.db_version))
                 and tri.data_ptr() == self.tri.data_ptr() and tri.shape == self.tri.shape
                 and attr.shape[-2] == self.pos.shape[-2])
 
@@ -150,7 +154,7 @@ class _RasterizeOp:
     def forward(raster_ctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
         state = raster_ctx.cpp_wrapper
         rast, rast_db = _plugin.rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx)
-        origin = rast._nvdr_origin = _RasterOrigin(pos, tri, state, rast, state.last_flags)
+        origin = rast._nvdr_origin = _RasterOrigin(pos, tri, state, rast, state.last_flags, rast_db, grad_db)
         return (rast, rast_db), (pos, tri, rast), (bool(grad_db), origin)
 
     @staticmethod
@@ -158,8 +162,12 @@ class _RasterizeOp:
         grad_db, origin = state
         pos, tri, rast = saved
         if origin is not None and origin.pending is not None:
-            (g_rast, ptr, version, g_pos), origin.pending = origin.pending, None
-            if (d_rast is not None and (d_rast_db is None or not grad_db)
+            (g_rast, ptr, version, g_pos, g_db), origin.pending = origin.pending, None
+            # the prepared gradient stands if what arrives for rast is interpolate's own g_rast and what arrives for rast_db is
+            # nothing (plain interpolation), irrelevant (grad_db=False) or interpolate's own g_rast_db
+            db_ok = (d_rast_db is None and g_db is None) or not grad_db or \
+                    (g_db is not None and d_rast_db is not None and d_rast_db.data_ptr() == g_db[1] and d_rast_db._version == g_db[2])
+            if (d_rast is not None and db_ok
                     and d_rast.data_ptr() == ptr and d_rast._version == version and d_rast.shape == g_rast.shape):
                 _plugin.fused_backward_count("used")
                 return None, g_pos, None, None, None, None, None
@@ -203,8 +211,8 @@ class _InterpolateOp:
         came straight from rasterize() and this is its only interpolation (see _RasterOrigin)."""
         flags = None if origin is None else origin.flags_for(rast)
         if origin is not None and origin.usable_by(attr, rast, tri):
-            g_attr, g_rast, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, tile_flags=flags)
-            origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos)
+            g_attr, g_rast, _, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, tile_flags=flags)
+            origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos, None)
             return g_attr, g_rast
         return _plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)
 
@@ -219,8 +227,17 @@ class _InterpolateOp:
             return g_attr, g_rast, None, None, None, None
         if with_da:
             attr, rast, tri, rast_db = saved
+            flags = None if origin is None else origin.flags_for(rast)
+            if origin is not None and origin.usable_by(attr, rast, tri, rast_db):
+                # config 3's pair: interpolate_grad_da + rasterize_grad_db in one pass (see _RasterOrigin)
+                g_attr, g_rast, g_rast_db, g_pos = _plugin.interpolate_rasterize_grad(
+                    attr, rast, tri, origin.pos, d_out, tile_flags=flags, rast_db=rast_db, dda=d_out_da,
+                    diff_attrs_all=diff_all, diff_attrs_vec=diff_list, db_to_pos=origin.grad_db)
+                origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos,
+                                  (g_rast_db, g_rast_db.data_ptr(), g_rast_db._version))
+                return g_attr, g_rast, None, g_rast_db, None, None
             g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
-                                                                    tile_flags=None if origin is None else origin.flags_for(rast))
+                                                                    tile_flags=flags)
             return g_attr, g_rast, None, g_rast_db, None, None
         attr, rast, tri = saved
         g_attr, g_rast = _InterpolateOp._plain_grad(attr, rast, tri, d_out, origin)

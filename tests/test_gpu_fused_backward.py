@@ -44,7 +44,7 @@ def test_fused_kernel_against_the_oracle(dr, oracle, A, attr_mode, with_g_rast):
     ro, _ = oracle.rasterize(b["pos"], b["tri"], res)
     ga, gr, _ = oracle.interpolate_grad(attr, ro, b["tri"], dy)
     gp = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr)
-    g_attr, g_rast, g_pos = _plugin.interpolate_rasterize_grad(_t(attr), _t(ro), _t(b["tri"]), _t(b["pos"]), _t(dy), with_g_rast=with_g_rast)
+    g_attr, g_rast, _, g_pos = _plugin.interpolate_rasterize_grad(_t(attr), _t(ro), _t(b["tri"]), _t(b["pos"]), _t(dy), with_g_rast=with_g_rast)
     within("fused: g_attr", g_attr.cpu().numpy(), ga, grad_tol(ga))
     within("fused: g_pos", g_pos.cpu().numpy(), gp, grad_tol(gp))
     if with_g_rast:
@@ -72,7 +72,7 @@ def test_fused_kernel_in_range_mode_and_with_non_finite_gradients(dr, oracle):
     dy = rng.normal(size=(2,) + res + (4,)).astype(np.float32)
     ga, gr, _ = oracle.interpolate_grad(attr, ro, tri, dy)
     gp = oracle.rasterize_grad(pos, tri, ro, gr)
-    g_attr, g_rast, g_pos = _plugin.interpolate_rasterize_grad(_t(attr), _t(ro), _t(tri), _t(pos), _t(dy))
+    g_attr, g_rast, _, g_pos = _plugin.interpolate_rasterize_grad(_t(attr), _t(ro), _t(tri), _t(pos), _t(dy))
     within("fused range mode: g_attr", g_attr.cpu().numpy(), ga, grad_tol(ga))
     within("fused range mode: g_pos", g_pos.cpu().numpy(), gp, grad_tol(gp))
     within("fused range mode: g_rast", g_rast.cpu().numpy(), gr, grad_tol(gr))
@@ -81,7 +81,7 @@ def test_fused_kernel_in_range_mode_and_with_non_finite_gradients(dr, oracle):
     covered = np.argwhere(ro[0, ..., 3] > 0)
     y, x = covered[len(covered) // 2]
     dy2 = dy.copy(); dy2[0, y, x, 1] = np.inf
-    f_attr, f_rast, f_pos = _plugin.interpolate_rasterize_grad(_t(attr), _t(ro), _t(tri), _t(pos), _t(dy2))
+    f_attr, f_rast, _, f_pos = _plugin.interpolate_rasterize_grad(_t(attr), _t(ro), _t(tri), _t(pos), _t(dy2))
     s_attr, s_rast = _plugin.interpolate_grad(_t(attr), _t(ro), _t(tri), _t(dy2))
     s_pos = _plugin.rasterize_grad(_t(pos), _t(tri), _t(ro), s_rast)
     assert torch.equal(torch.isfinite(f_attr), torch.isfinite(s_attr)) and torch.equal(torch.isfinite(f_pos), torch.isfinite(s_pos))
@@ -201,3 +201,74 @@ def test_fused_backward_inside_a_captured_graph(dr, oracle):
     within("fused in a graph: g_attr", attr.grad.cpu().numpy(), ga, grad_tol(ga))
     assert torch.allclose(pos.grad, eager_pos, rtol=1e-5, atol=1e-5 * float(eager_pos.abs().max()))
     assert torch.allclose(attr.grad, eager_attr, rtol=1e-5, atol=1e-5 * float(eager_attr.abs().max()))
+
+
+@pytest.mark.parametrize("A,diff,db_to_pos", [(2, "all", True), (3, [0, -1], True), (4, [2], True), (2, "all", False), (5, "all", True)])
+def test_fused_kernel_with_pixel_differentials_against_the_oracle(dr, oracle, A, diff, db_to_pos):
+    """interpolate_grad_da + rasterize_grad_db in one kernel (config 3's backward pair): attribute gradients through the
+    values AND the differentials, g_rast, g_rast_db, and the position gradient with (or, for grad_db=False, without) the
+    rast_db term."""
+    from nvdiffrast_amd.torch import _plugin
+    N, res = 2, (120, 168)
+    b = m10k_batch(N, seed=35, nx=30, ny=15)
+    rng = np.random.default_rng(10 + A)
+    V = b["pos"].shape[1]
+    attr = rng.uniform(-1, 1, size=(1, V, A)).astype(np.float32)
+    D = A if diff == "all" else len(diff)
+    dy = rng.normal(size=(N,) + res + (A,)).astype(np.float32)
+    dda = rng.normal(size=(N,) + res + (2 * D,)).astype(np.float32)
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    ga, gr, grdb = oracle.interpolate_grad(attr, ro, b["tri"], dy, rdbo, dda, diff)
+    gp = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr, grdb if db_to_pos else None)
+    g_attr, g_rast, g_rast_db, g_pos = _plugin.interpolate_rasterize_grad(
+        _t(attr), _t(ro), _t(b["tri"]), _t(b["pos"]), _t(dy), rast_db=_t(rdbo), dda=_t(dda),
+        diff_attrs_all=(diff == "all"), diff_attrs_vec=([] if diff == "all" else diff), db_to_pos=db_to_pos)
+    within("fused da: g_attr", g_attr.cpu().numpy(), ga, grad_tol(ga))
+    within("fused da: g_rast", g_rast.cpu().numpy(), gr, grad_tol(gr))
+    within("fused da: g_rast_db", g_rast_db.cpu().numpy(), grdb, grad_tol(grdb))
+    within("fused da: g_pos", g_pos.cpu().numpy(), gp, grad_tol(gp))
+
+
+def test_operator_layer_fuses_the_differential_pair_too(dr, oracle):
+    """rasterize -> interpolate(diff_attrs='all') -> (something per pixel) -> loss: one backward kernel for the pair, unless
+    rast_db's gradient has another contributor."""
+    from nvdiffrast_amd import _capi
+    lib = _capi.load()
+    N, res = 2, (128, 128)
+    b = m10k_batch(N, seed=36, nx=30, ny=15, attrs=2)
+    rng = np.random.default_rng(4)
+    G = rng.normal(size=(N,) + res + (2,)).astype(np.float32)
+    Gd = rng.normal(size=(N,) + res + (4,)).astype(np.float32)
+    tri = _t(b["tri"])
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    ga, gr, grdb = oracle.interpolate_grad(b["uv"], ro, b["tri"], G, rdbo, Gd, "all")
+    gp = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr, grdb)
+    got = {}
+
+    def step(ctx, extra=None, grad_db=True):
+        pos = _t(b["pos"]).requires_grad_(True)
+        uv = _t(b["uv"]).requires_grad_(True)
+        rast, rast_db = dr.rasterize(ctx, pos, tri, res, grad_db=grad_db)
+        out, out_da = dr.interpolate(uv, rast, tri, rast_db=rast_db, diff_attrs="all")
+        loss = (out * _t(G)).sum() + (out_da * _t(Gd)).sum()
+        if extra is not None:
+            loss = loss + extra(rast_db)
+        loss.backward()
+        got["pos"], got["uv"] = pos.grad, uv.grad
+
+    ctx = dr.RasterizeCudaContext()
+    names = _kernels(lib, _capi, lambda: step(ctx))
+    assert "interp_raster_grad_da" in names and not ({"raster_grad_db", "interp_grad_da"} & names), names
+    within("fused da autograd: g_pos", got["pos"].cpu().numpy(), gp, grad_tol(gp))
+    within("fused da autograd: g_uv", got["uv"].cpu().numpy(), ga, grad_tol(ga))
+    # grad_db=False: the differentials' gradient stops at rast_db
+    gp_nodb = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr)
+    names = _kernels(lib, _capi, lambda: step(dr.RasterizeCudaContext(), grad_db=False))
+    assert "interp_raster_grad_da" in names and "raster_grad" not in names, names
+    within("fused da, grad_db=False: g_pos", got["pos"].cpu().numpy(), gp_nodb, grad_tol(gp_nodb))
+    # a second contributor to rast_db's gradient: discarded, recomputed from the sum
+    w = rng.normal(size=(N,) + res + (4,)).astype(np.float32)
+    gp2 = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr, grdb + w)
+    names = _kernels(lib, _capi, lambda: step(ctx, lambda rdb: (rdb * _t(w)).sum()))
+    assert "interp_raster_grad_da" in names and "raster_grad_db" in names, names
+    within("discarded fused da: g_pos", got["pos"].cpu().numpy(), gp2, grad_tol(gp2))
