@@ -784,7 +784,15 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     if (kPlain && it4.y == 0) {
         const int nz = p.chunkNz[xcd];
         if (jj - nz < nz) return;                                          // cleared by the chunk's (jj - nz)-th bin
-    }                                                                      // (an empty bin without a partner takes the common path)
+        // an empty bin without a partner (more empty bins than others in the chunk): zeros straight away -- no key arrays, no
+        // shader; its waves take their tile rows from a ticket like the partner-clearing epilogue does
+        if (threadIdx.x == 0) sh.ticket = 0;
+        __syncthreads();
+        int row = 0;
+        if ((threadIdx.x & 63) == 0) row = atomicAdd(&sh.ticket, 1);
+        clear_bin(it4.z, __builtin_amdgcn_readfirstlane(row));
+        return;
+    }
     const int n   = work / binsPerImage;
     const int bin = work - n * binsPerImage;
     const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
@@ -1449,7 +1457,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.splitInfo = (const int*)(sb + L.splitInfo); fp.helpers = (const int4*)(sb + L.helpers);
         fp.splitKeys = (unsigned long long*)(sb + L.splitKeys); fp.splitDone = (int*)(sb + L.splitDone);
         fp.chunkNz = (const int*)(sb + L.poolPeak + 16);                                        // 8 ints behind the pool-demand counter
-        fp.tileFlags = tile_flags; fp.tfW = (W + 7) >> 3; fp.tfH = (H + 7) >> 3;
+        fp.tileFlags = (debug_flags() & 67108864) ? nullptr : tile_flags; fp.tfW = (W + 7) >> 3; fp.tfH = (H + 7) >> 3;   // (timing switch; use with 33554432)
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
