@@ -177,12 +177,16 @@ int nvdr_texture_mip_info(int tex_n, int tex_h, int tex_w, int C, int cube, int 
 int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h, int tex_w, int C, int cube,
                                int max_mip_level, float* mip, nvdrStream_t stream);
 
+/* tile_flags of the two texture entry points (optional, NULL = none; 2-D textures only): the rasterizer's occupancy flags
+ * for the image that uv / uv_da were interpolated over -- in a tile flagged 0 both are KNOWN to be zero (interpolate writes
+ * zeros where no triangle is visible) and are not read.  Only legal while uv and uv_da are exactly what the interpolate
+ * call for that rast wrote (the operator layer checks identity and version). */
 /* mip_ptrs_host: HOST array of L device pointers (levels 1..L; the wrapper's flat buffer plus
  * offsets, or the tensors of a custom stack); NULL / L = 0 for the non-mipmapped filters. */
 int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_host, int L,
                      const float* uv, const float* uv_da, const float* mip_level_bias,
                      int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
-                     int filter_mode, int boundary_mode, float* out, nvdrStream_t stream);
+                     int filter_mode, int boundary_mode, float* out, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* g_tex (shape of tex) and every g_mip level must be zero-filled by the caller
  * (torch_texture.cpp:523,583-604); g_uv [N,H,W,2] (NULL for nearest), g_uv_da [N,H,W,4] and
@@ -200,7 +204,7 @@ int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_host, int L
                       int filter_mode, int boundary_mode, int pull_mip_grads,
                       float* g_tex, float* const* g_mip_ptrs_host,
                       float* g_uv, float* g_uv_da, float* g_mip_level_bias,
-                      void* scratch, size_t scratch_bytes, nvdrStream_t stream);
+                      void* scratch, size_t scratch_bytes, const uint8_t* tile_flags, nvdrStream_t stream);
 
 /* ---- antialias ------------------------------------------------------------------
  * Replaces antialias_construct_topology_hash / antialias_fwd / antialias_grad

@@ -50,11 +50,11 @@ SIGNATURES = {
     "nvdr_texture_mip_info": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, _intp, _intp, _i64p, _i64p]),
     "nvdr_texture_construct_mip": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nvdr_texture_fwd": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                 c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "nvdr_texture_grad_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "nvdr_texture_grad": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_void_p, _vpp, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  c_void_p, _vpp, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "nvdr_antialias_hash_bytes": (c_size_t, [c_int]),
     "nvdr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nvdr_antialias_construct_topology_hash": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

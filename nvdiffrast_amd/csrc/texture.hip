@@ -40,6 +40,10 @@ struct TexParams {
     // k_tex_grad_fold merges the records (a constant-uv background produces ONE texel quad for hundreds of thousands of
     // waves) and adds the totals to the gradient texture.
     int* rec; int nrec;
+    // Tiles (8x8 pixels) in which uv and uv_da are KNOWN to be zero: the rasterizer's occupancy flags, handed on by the
+    // operator layer when uv / uv_da are interpolate()'s own, untouched outputs for that rast (nvdr_device.hpp TileFlags;
+    // f == nullptr: nothing known).  Pixels of such tiles take uv = 0, uv_da = 0 without reading them.
+    TileFlags zflags;
 };
 
 constexpr int kTexRecHeader = 8;                  // words per record in front of the channel totals
@@ -303,7 +307,7 @@ __device__ __forceinline__ void cube_grad4(float3 v, float4 dw, float3& g0, floa
 // texture_kernel.cu:477-585
 template <int FILTER, bool BIAS_ONLY, bool CUBE = false>
 __device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, int& level0, int& level1, float& flevel, float4* dw,
-                                              float3 uv3 = make_float3(0.f, 0.f, 0.f), float3* dfdv = nullptr)
+                                              float3 uv3 = make_float3(0.f, 0.f, 0.f), float3* dfdv = nullptr, bool zeroDA = false)
 {
 #pragma clang fp contract(off)
     level0 = 0; level1 = 0; flevel = 0.f;
@@ -317,7 +321,7 @@ __device__ __forceinline__ void tex_mip_level(const TexParams& p, size_t pidx, i
             dvdX = make_float3(d0.x, d1.x, d2.x); dvdY = make_float3(d0.y, d1.y, d2.y);
             d = cube_grad_st(uv3, dvdX, dvdY);
         } else {
-            d = ((const float4*)p.uvDA)[pidx];
+            d = zeroDA ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)p.uvDA)[pidx];
         }
         const float uscl = (float)p.texW, vscl = (float)p.texH;
         const float dsdx = d.x * uscl, dsdy = d.y * uscl, dtdx = d.z * vscl, dtdy = d.w * vscl;
@@ -446,7 +450,8 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
     const int C = C_CT > 0 ? C_CT : p.channels;
     const int tz = (p.texDepth == 1) ? 0 : pz;
     const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
-    const float2 uv = ((const float2*)p.uv)[pidx];
+    const bool zt = p.zflags.empty(pz, py, px);               // uv = uv_da = 0 known for this tile: not read
+    const float2 uv = zt ? make_float2(0.f, 0.f) : ((const float2*)p.uv)[pidx];
     float* pOut = p.out + pidx * C;
 
     if (FILTER == TEX_NEAREST) {
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
     }
 
     int level0, level1; float flevel;
-    tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, nullptr);
+    tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, nullptr, make_float3(0.f, 0.f, 0.f), nullptr, zt);
     const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
     const float* pIn0 = p.tex[level0];
     const bool second = (FILTER == TEX_LML) && flevel > 0.f;
@@ -644,6 +649,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     const int tz = (p.texDepth == 1) ? 0 : pz;
     const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
     const float* pDy = p.dy + pidx * C;
+    const bool zt = !CUBE && inside && p.zflags.empty(pz, py, px);   // uv = uv_da = 0 known for this tile: not read
 
     // ---- phase A: all-zero upstream gradients take the early-out (explicit zero stores, :922-971);
     //      the rest publish the block's largest |dy|.
@@ -734,11 +740,11 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     bool uniformWave = false;
     if (!CUBE && !direct && !(p.dbg & (1024 | 4096)) && (FILTER == TEX_LINEAR || ((FILTER == TEX_LMN || FILTER == TEX_LML) && !BIAS_ONLY))) {
         if (__ballot(active) == ~0ull) {
-            const float2 t = ((const float2*)p.uv)[pidx];
+            const float2 t = zt ? make_float2(0.f, 0.f) : ((const float2*)p.uv)[pidx];
             const int ux = __float_as_int(t.x), uy = __float_as_int(t.y);
             bool same = (ux == __builtin_amdgcn_readfirstlane(ux)) & (uy == __builtin_amdgcn_readfirstlane(uy));
             if (FILTER != TEX_LINEAR) {
-                const float4 d = ((const float4*)p.uvDA)[pidx];
+                const float4 d = zt ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)p.uvDA)[pidx];
                 same &= (d.x == 0.f) & (d.y == 0.f) & (d.z == 0.f) & (d.w == 0.f);
                 if (p.bias) same &= !(fabsf(p.bias[pidx]) == INFINITY);          // -inf + inf would be NaN, not -inf
             }
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     }
     if (uniformWave) {
         const int lane = threadIdx.x & 63;
-        const float2 t = ((const float2*)p.uv)[pidx];
+        const float2 t = zt ? make_float2(0.f, 0.f) : ((const float2*)p.uv)[pidx];
         const Quad q0 = tex_index_linear(p, t.x, t.y, tz, 0);
         const float* pIn0 = p.tex[0];
         const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     if (active && !uniformWave) {
         float3 uv3 = make_float3(0.f, 0.f, 0.f);
         if (CUBE) { const float* q = p.uv + pidx * 3; uv3 = make_float3(q[0], q[1], q[2]); }
-        else { const float2 t = ((const float2*)p.uv)[pidx]; uv3 = make_float3(t.x, t.y, 0.f); }
+        else { const float2 t = zt ? make_float2(0.f, 0.f) : ((const float2*)p.uv)[pidx]; uv3 = make_float3(t.x, t.y, 0.f); }
         auto footprint = [&](int level) { return CUBE ? tex_index_linear_cube(p, uv3, tz, level) : tex_index_linear(p, uv3.x, uv3.y, tz, level); };
 
         if (FILTER == TEX_NEAREST) {
@@ -834,7 +840,7 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
             float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
             float3 dfdv = make_float3(0.f, 0.f, 0.f);
             int level0, level1; float flevel;
-            tex_mip_level<FILTER, BIAS_ONLY, CUBE>(p, pidx, level0, level1, flevel, &dw, uv3, &dfdv);
+            tex_mip_level<FILTER, BIAS_ONLY, CUBE>(p, pidx, level0, level1, flevel, &dw, uv3, &dfdv, zt);
 
             const Quad q0 = footprint(level0);
             const float* pIn0 = p.tex[level0];
@@ -1447,7 +1453,7 @@ extern "C" int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h
 extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_host, int L,
                                 const float* uv, const float* uv_da, const float* mip_level_bias,
                                 int tex_n, int tex_h, int tex_w, int C, int N, int H, int W,
-                                int filter_mode, int boundary_mode, float* out, nvdrStream_t stream_)
+                                int filter_mode, int boundary_mode, float* out, const uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     TexParams p;
@@ -1456,6 +1462,7 @@ extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_h
     if (rc) return rc;
     NVDR_REQUIRE(out, "texture_fwd: null output");
     p.out = out;
+    if (boundary_mode != TEX_B_CUBE && !(debug_flags() & 33554432)) p.zflags = TileFlags{tile_flags, (W + 7) >> 3, (H + 7) >> 3};
     bool vec4 = (C == 4) && !((uintptr_t)out & 15), vec2 = (C == 2) && !((uintptr_t)out & 7);
     for (int i = 0; i <= p.levelMax; i++) { vec4 = vec4 && !((uintptr_t)p.tex[i] & 15); vec2 = vec2 && !((uintptr_t)p.tex[i] & 7); }
     const dim3 grid = tex_grid(p);
@@ -1496,7 +1503,7 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
                                  int filter_mode, int boundary_mode, int pull_mip_grads,
                                  float* g_tex, float* const* g_mip_ptrs_host,
                                  float* g_uv, float* g_uv_da, float* g_mip_level_bias,
-                                 void* scratch, size_t scratch_bytes, nvdrStream_t stream_)
+                                 void* scratch, size_t scratch_bytes, const uint8_t* tile_flags, nvdrStream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     TexParams p;
@@ -1513,6 +1520,7 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
         NVDR_REQUIRE(!((uintptr_t)g_uv_da & 7), "grad_uv_da output tensor not aligned to float2");
     }
     p.dy = dy;
+    if (!cube && !(debug_flags() & 33554432)) p.zflags = TileFlags{tile_flags, (W + 7) >> 3, (H + 7) >> 3};
     p.gradTex[0] = g_tex;
     for (int i = 1; i <= p.levelMax; i++) {
         NVDR_REQUIRE(g_mip_ptrs_host && g_mip_ptrs_host[i - 1], "texture_grad: gradient buffer of mip level %d missing", i);

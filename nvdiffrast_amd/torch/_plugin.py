@@ -732,7 +732,7 @@ def _texture_common(fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, 
     return dev, enable_mip, has_uv_da, has_bias, levels, g_levels, g_flat
 
 
-def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode):
+def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:174-407."""
     fn = "texture_fwd_mip"
     dev, enable_mip, has_uv_da, has_bias, levels, _, _ = _texture_common(
@@ -746,17 +746,18 @@ def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filt
                                            uv_da.data_ptr() if (enable_mip and has_uv_da) else None,
                                            mip_level_bias.data_ptr() if (enable_mip and has_bias) else None,
                                            tn, th, tw, C, n, H, W,
-                                           int(filter_mode), int(boundary_mode), out.data_ptr(), _stream(dev))
+                                           int(filter_mode), int(boundary_mode), out.data_ptr(),
+                                           _flags_ok(fn, tile_flags, n, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
     return out
 
 
-def texture_fwd(tex, uv, filter_mode, boundary_mode):
+def texture_fwd(tex, uv, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:411-416."""
-    return texture_fwd_mip(tex, uv, None, None, None, [], filter_mode, boundary_mode)
+    return texture_fwd_mip(tex, uv, None, None, None, [], filter_mode, boundary_mode, tile_flags)
 
 
-def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode):
+def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:421-690 -> (g_tex, g_uv, g_uv_da, g_mip_level_bias, [g_mip...])."""
     fn = "texture_grad_linear_mipmap_linear"
     mip_stack = list(mip_stack)
@@ -793,25 +794,26 @@ def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wr
                                             dy_.data_ptr(), tn, th, tw, C, n, H, W,
                                             int(filter_mode), int(boundary_mode), int(enable_mip and not has_stack),
                                             g_tex.data_ptr(), gptrs, _capi.ptr(g_uv), _capi.ptr(g_uv_da), _capi.ptr(g_bias),
-                                            _capi.ptr(scratch), 0 if scratch is None else scratch.numel() * 4, _stream(dev))
+                                            _capi.ptr(scratch), 0 if scratch is None else scratch.numel() * 4,
+                                            _flags_ok(fn, tile_flags, n, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
     return g_tex, g_uv, g_uv_da, g_bias, (g_levels if has_stack else [])
 
 
-def texture_grad_nearest(tex, uv, dy, filter_mode, boundary_mode):
+def texture_grad_nearest(tex, uv, dy, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:692-698."""
-    return texture_grad_linear_mipmap_linear(tex, uv, dy, None, None, None, [], filter_mode, boundary_mode)[0]
+    return texture_grad_linear_mipmap_linear(tex, uv, dy, None, None, None, [], filter_mode, boundary_mode, tile_flags)[0]
 
 
-def texture_grad_linear(tex, uv, dy, filter_mode, boundary_mode):
+def texture_grad_linear(tex, uv, dy, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:700-706."""
-    r = texture_grad_linear_mipmap_linear(tex, uv, dy, None, None, None, [], filter_mode, boundary_mode)
+    r = texture_grad_linear_mipmap_linear(tex, uv, dy, None, None, None, [], filter_mode, boundary_mode, tile_flags)
     return r[0], r[1]
 
 
-def texture_grad_linear_mipmap_nearest(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode):
+def texture_grad_linear_mipmap_nearest(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:708-713."""
-    r = texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode)
+    r = texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, tile_flags)
     return r[0], r[1], r[4]
 
 

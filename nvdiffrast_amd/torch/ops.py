@@ -147,6 +147,27 @@ class _RasterOrigin:
                 and attr.shape[-2] == self.pos.shape[-2])
 
 
+class _ZeroTiles:
+    """Carried by interpolate()'s outputs: `flags` (the rasterizer's tile occupancy) marks 8x8 tiles in which this tensor is
+    zero.  Valid while the tensor is untouched (same storage, same version counter)."""
+    __slots__ = ("flags", "ptr", "version")
+
+    def __init__(self, flags, t):
+        self.flags, self.ptr, self.version = flags, t.data_ptr(), t._version
+
+    @staticmethod
+    def of(uv, uv_da):
+        """The flags that texture(uv, uv_da) may use: both tensors (uv_da may be absent) zero on the same empty tiles."""
+        z = getattr(uv, "_nvdr_zero_tiles", None)
+        if z is None or uv.data_ptr() != z.ptr or uv._version != z.version:
+            return None
+        if uv_da is not None and uv_da.numel():
+            zd = getattr(uv_da, "_nvdr_zero_tiles", None)
+            if zd is None or zd.flags is not z.flags or uv_da.data_ptr() != zd.ptr or uv_da._version != zd.version:
+                return None
+        return z.flags
+
+
 class _RasterizeOp:
     """args: context, pos, tri, resolution, ranges, grad_db, peeling_idx -> (rast, rast_db); gradient to pos only."""
 
@@ -203,6 +224,12 @@ class _InterpolateOp:
             keep = (attr, rast, tri)
         if origin is not None:
             origin.interpolations += 1
+        if flags is not None:
+            # interpolate writes zeros where no triangle is visible: the rasterizer's empty tiles are tiles of zeros in both
+            # outputs, and texture() may skip reading them there (as long as the tensors stay what they are now)
+            for t in outs:
+                if t.numel():
+                    t._nvdr_zero_tiles = _ZeroTiles(flags, t)
         return tuple(outs), keep, (with_da, diff_all, diff_list, origin)
 
     @staticmethod
@@ -252,40 +279,43 @@ class _TextureOp:
     @staticmethod
     def forward(filter_mode, boundary, tex, uv, uv_da, mip_level_bias, mip_wrapper, *mip_stack):
         f = _FILTER_MODES[filter_mode]
+        zf = None if boundary == _BOUNDARY_MODES["cube"] else _ZeroTiles.of(uv, uv_da)      # tiles of known-zero uv / uv_da
         if filter_mode in _MIPMAPPED:
             # absent optional tensors travel as empty tensors, an absent wrapper as an empty one (ops.py:301-307)
             placeholder = torch.tensor([])
             uv_da = placeholder if uv_da is None else uv_da
             mip_level_bias = placeholder if mip_level_bias is None else mip_level_bias
             mip_wrapper = _plugin.TextureMipWrapper() if mip_wrapper is None else mip_wrapper
-            out = _plugin.texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, f, boundary)
+            out = _plugin.texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, f, boundary, tile_flags=zf)
             keep = (tex, uv, uv_da, mip_level_bias) + tuple(mip_stack)
         else:
-            out = _plugin.texture_fwd(tex, uv, f, boundary)
+            out = _plugin.texture_fwd(tex, uv, f, boundary, tile_flags=zf)
             keep = (tex, uv)
-        return out, keep, (filter_mode, f, boundary, mip_wrapper, len(mip_stack))
+        return out, keep, (filter_mode, f, boundary, mip_wrapper, len(mip_stack), zf)
 
     @staticmethod
     def backward(state, saved, d_out):
-        filter_mode, f, boundary, mip_wrapper, n_custom = state
+        filter_mode, f, boundary, mip_wrapper, n_custom, zf = state
         g_uv = g_uv_da = g_bias = None
         g_levels = (None,) * n_custom
+        if zf is not None and _ZeroTiles.of(saved[1], saved[2] if filter_mode in _MIPMAPPED else None) is not zf:
+            zf = None                                         # uv / uv_da were written to since the forward pass
         if filter_mode in _MIPMAPPED:
             tex, uv, uv_da, bias = saved[:4]
             stack = list(saved[4:])
             if filter_mode == "linear-mipmap-linear":
                 g_tex, g_uv, g_uv_da, g_bias, g_stack = _plugin.texture_grad_linear_mipmap_linear(
-                    tex, uv, d_out, uv_da, bias, mip_wrapper, stack, f, boundary)
+                    tex, uv, d_out, uv_da, bias, mip_wrapper, stack, f, boundary, tile_flags=zf)
             else:
                 g_tex, g_uv, g_stack = _plugin.texture_grad_linear_mipmap_nearest(
-                    tex, uv, d_out, uv_da, bias, mip_wrapper, stack, f, boundary)
+                    tex, uv, d_out, uv_da, bias, mip_wrapper, stack, f, boundary, tile_flags=zf)
             g_levels = tuple(g_stack)
         else:
             tex, uv = saved
             if filter_mode == "linear":
-                g_tex, g_uv = _plugin.texture_grad_linear(tex, uv, d_out, f, boundary)
+                g_tex, g_uv = _plugin.texture_grad_linear(tex, uv, d_out, f, boundary, tile_flags=zf)
             else:
-                g_tex = _plugin.texture_grad_nearest(tex, uv, d_out, f, boundary)
+                g_tex = _plugin.texture_grad_nearest(tex, uv, d_out, f, boundary, tile_flags=zf)
         return (None, None, g_tex, g_uv, g_uv_da, g_bias, None) + g_levels
 
 

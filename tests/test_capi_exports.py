@@ -73,9 +73,9 @@ def test_texture_and_antialias_host_side(lib):
     assert lib.nvdr_antialias_hash_bytes(1) == 64 * 8 * 16
     assert lib.nvdr_antialias_work_bytes(2, 16, 8) == (2 * 16 * 8 * 8 + 4) * 4
     # argument errors come back as codes + messages before anything is launched
-    rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 1, 1, None, None)
+    rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 1, 1, None, None, None)
     assert rc == 1 and b"null pointer" in lib.nvdr_last_error()
-    rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 7, 1, None, None)
+    rc = lib.nvdr_texture_fwd(None, None, 0, None, None, None, 1, 4, 4, 3, 1, 2, 2, 7, 1, None, None, None)
     assert rc == 1 and b"filter_mode unsupported" in lib.nvdr_last_error()
     rc = lib.nvdr_antialias_fwd(None, None, None, None, None, 0, 1, 1, 3, 1, 4, 4, 3, None, None, 0, None, None)
     assert rc == 1 and b"null pointer" in lib.nvdr_last_error()

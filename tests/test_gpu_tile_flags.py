@@ -107,3 +107,58 @@ def test_consumers_skip_empty_tiles_only_for_the_untouched_rast(dr, oracle):
     within("edited rast: interpolate", o2.cpu().numpy(), want, ATOL)
     # a copy of rast has no flags either (nothing is assumed about tensors the rasterizer did not hand out itself)
     assert getattr(rast.detach().clone(), "_nvdr_origin", None) is None
+
+
+@pytest.mark.parametrize("fm", ["nearest", "linear", "linear-mipmap-nearest", "linear-mipmap-linear"])
+@pytest.mark.parametrize("bm", ["wrap", "clamp", "zero"])
+def test_texture_takes_uv_of_empty_tiles_as_zero_only_while_it_is(dr, oracle, fm, bm):
+    """interpolate()'s outputs carry the rasterizer's flags (zeros on empty tiles); texture() forward and backward then do
+    not read uv / uv_da there.  Same results as the oracle on the full tensors; after an in-place edit of uv inside an empty
+    tile the flags are dropped and the edit shows."""
+    N, res = 2, (96, 128)
+    b = m10k_batch(N, seed=71, nx=20, ny=10, attrs=2)
+    pos_np = b["pos"].copy(); pos_np[..., :2] *= 0.55
+    rng = np.random.default_rng(8)
+    tex_np = rng.uniform(size=(1, 64, 64, 3)).astype(np.float32)
+    dy = rng.normal(size=(N,) + res + (3,)).astype(np.float32)
+    tri = _t(b["tri"])
+    ctx = dr.RasterizeCudaContext()
+    mip = "mipmap" in fm
+    ro, rdbo = oracle.rasterize(pos_np, b["tri"], res)
+    uvo, uvdao = oracle.interpolate(b["uv"], ro, b["tri"], rdbo, "all")
+
+    def run(edit=None):
+        rast, rast_db = dr.rasterize(ctx, _t(pos_np), tri, res)
+        uv, uv_da = dr.interpolate(_t(b["uv"]), rast, tri, rast_db=rast_db, diff_attrs="all")
+        assert uv._nvdr_zero_tiles.flags is rast._nvdr_origin.flags and uv_da._nvdr_zero_tiles.flags is uv._nvdr_zero_tiles.flags
+        if edit is not None:
+            with torch.no_grad():
+                edit(uv)
+        uv.requires_grad_(True); uv_da.requires_grad_(True)
+        tex = _t(tex_np).requires_grad_(True)
+        col = dr.texture(tex, uv, uv_da if mip else None, filter_mode=fm, boundary_mode=bm)
+        col.backward(_t(dy))
+        return col, tex.grad, uv.grad, (uv_da.grad if fm == "linear-mipmap-linear" else None), rast
+
+    col, g_tex, g_uv, g_da, rast = run()
+    kw = dict(filter_mode=fm, boundary_mode=bm)
+    want = oracle.texture(tex_np, uvo, uvdao if mip else None, **kw)
+    g = oracle.texture_grad(tex_np, uvo, dy, uvdao if mip else None, **kw)
+    within("zero tiles: texture", col.detach().cpu().numpy(), want, ATOL)
+    within("zero tiles: g_tex", g_tex.cpu().numpy(), g["tex"], grad_tol(g["tex"]))
+    if fm != "nearest":
+        within("zero tiles: g_uv", g_uv.cpu().numpy(), g["uv"], grad_tol(g["uv"]))
+    if g_da is not None:
+        within("zero tiles: g_uv_da", g_da.cpu().numpy(), g["uv_da"], grad_tol(g["uv_da"]))
+
+    flags = rast._nvdr_origin.flags
+    e = torch.nonzero(flags[1] == 0)[0]
+    ty, tx = int(e[0]), int(e[1])
+
+    def paint(uv):
+        uv[1, ty * 8 + 1, tx * 8 + 5] = torch.tensor([0.43, 0.27], device="cuda")
+    col2 = run(paint)[0]
+    uv2 = uvo.copy(); uv2[1, ty * 8 + 1, tx * 8 + 5] = (0.43, 0.27)
+    want2 = oracle.texture(tex_np, uv2, uvdao if mip else None, **kw)
+    assert np.abs(want2 - want).max() > 1e-3
+    within("zero tiles dropped: texture", col2.detach().cpu().numpy(), want2, ATOL)
