@@ -466,7 +466,7 @@ def window_stats(host_s, evt_ms, steps):
                           "on the launch stream around the same steps"}
 
 
-def extra_config(name, dev, steps, warmup, windows, with_cpu):
+def extra_config(name, dev, steps, warmup, windows, with_cpu, graph_too=False):
     """One more BASELINE config measured in this process (single GPU): the block that goes under `configs`."""
     wl = WORKLOADS[name]
     N = wl["per_gpu"]
@@ -482,6 +482,25 @@ def extra_config(name, dev, steps, warmup, windows, with_cpu):
     if with_cpu:
         cpu, cpu_ref = job.cpu_baselines(4 if job.full else 16)
         block["cpu_baseline"], block["cpu_reference"] = cpu, cpu_ref
+    if graph_too:
+        # the same step replayed from ONE hipGraph (nothing on the path allocates at the C-ABI level or synchronises the
+        # host, so the whole step captures): what the kernels alone take when the host's launch work is out of the way
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    job.step()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                job.step()
+            host_g, evt_g = job.timed_windows(g.replay, warmup, steps, windows)
+            ms_g, _ = window_stats(host_g, evt_g, steps)
+            block["hipgraph_replay"] = {"ms_per_step": round(ms_g, 4), "value": round(P / (ms_g * 1e-3) / 1e6, 1)}
+            del g
+        except Exception as e:  # noqa: BLE001
+            block["hipgraph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
     del job
     torch.cuda.empty_cache()
     return block
@@ -495,6 +514,11 @@ def c5_standin():
     fit_texture_synth.fit(iters=10, res=512, ref_res=2048, tex_size=2048)                       # warm-up: allocations, scratch
     r = fit_texture_synth.fit(iters=200, res=512, ref_res=2048, tex_size=2048)
     r["what"] = "samples/fit_texture_synth.py: all four ops fwd+bwd + Adam per iteration, eager launching; stands in for samples/torch/earth.py"
+    try:
+        rg = fit_texture_synth.fit(iters=200, res=512, ref_res=2048, tex_size=2048, graph=True)
+        r["hipgraph_replay"] = {"iters_per_s": rg["iters_per_s"], "loss_last": rg["loss_last"]}
+    except Exception as e:  # noqa: BLE001
+        r["hipgraph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return r
 
 
@@ -668,7 +692,8 @@ def main():
             configs = {}
             for name, st in (("c2", 20), ("c3", 6)):
                 try:
-                    configs[name] = extra_config(name, dev, st, 3, 5, with_cpu=(name == "c3" and not args.no_cpu_baseline))
+                    configs[name] = extra_config(name, dev, st, 3, 5, with_cpu=(name == "c3" and not args.no_cpu_baseline),
+                                                 graph_too=(name == "c2"))
                 except Exception as e:  # noqa: BLE001
                     configs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
