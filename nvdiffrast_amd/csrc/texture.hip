@@ -44,6 +44,9 @@ struct TexParams {
     // operator layer when uv / uv_da are interpolate()'s own, untouched outputs for that rast (nvdr_device.hpp TileFlags;
     // f == nullptr: nothing known).  Pixels of such tiles take uv = 0, uv_da = 0 without reading them.
     TileFlags zflags;
+    // Two-kernel gradient pass (k_tex_grad_light first): one byte per 16x16-pixel block, 1 = the block is left to k_tex_grad,
+    // 0 = k_tex_grad_light has done all of it (k_tex_grad's workgroup leaves at once).  NULL = single-kernel pass.
+    uint8_t* heavy;
 };
 
 constexpr int kTexRecHeader = 8;                  // words per record in front of the channel totals
@@ -642,6 +645,10 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     int* s_used = (int*)(s_max + 4);                                        // [groups] indices of the used patches (flush)
     int px = 0, py = 0, pz = 0; bool inside;
     if (!tex_pixel(p, px, py, pz, inside)) return;
+    if (p.heavy) {                                               // two-kernel pass: blocks that k_tex_grad_light has finished
+        const int blk = (int)(blockIdx.x & 7) * ((p.tilesX * p.tilesY * p.n + 7) >> 3) + (int)(blockIdx.x >> 3);     // as tex_pixel
+        if (!p.heavy[blk]) return;
+    }
     if (groups > 0 && !(p.dbg & 2048)) tab.clear(threadIdx.x, 256);
     if (threadIdx.x == 0) { s_max[0] = 0u; s_max[1] = 0u; }
     __syncthreads();
@@ -979,6 +986,119 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         const int w = level_dim(p.texW, level), h = level_dim(p.texH, level) * (CUBE ? 6 : 1);
         if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
         atomic_add_f32(p.gradTex[level] + ((tz * h + y) * w + x) * C + c, fs.to_float(t));
+    }
+}
+
+// First kernel of the two-kernel gradient pass (2-D textures, bilinear footprints, caller scratch): everything that needs no
+// scatter machinery, at the occupancy of a streaming kernel.  k_tex_grad carries 96 VGPRs and a 26 KB table for its general
+// path, so five waves per SIMD is all a background pixel gets there -- and three quarters of a rendered image's pixels are
+// background (one texel quad, zero footprint: the uniform-wave path) or carry no upstream gradient at all (zero stores).
+// Here a 16x16-pixel block whose four waves are ALL of those two kinds is finished -- zero stores, the uv gradient of the
+// constant quad, one record per uniform wave for k_tex_grad_fold -- and marked 0 in `heavy`; a block with any other wave
+// (real footprints, partly active waves, inf / NaN gradients) is marked 1 and left entirely to k_tex_grad, untouched.
+template <int FILTER, int C_CT>
+__global__ __launch_bounds__(256, 8) void k_tex_grad_light(const TexParams p)
+{
+    __shared__ int s_heavy;
+    int px = 0, py = 0, pz = 0; bool inside;
+    if (!tex_pixel(p, px, py, pz, inside)) return;
+    const int blk = (int)(blockIdx.x & 7) * ((p.tilesX * p.tilesY * p.n + 7) >> 3) + (int)(blockIdx.x >> 3);         // as tex_pixel
+    if (threadIdx.x == 0) s_heavy = 0;
+    __syncthreads();
+    const int C = C_CT > 0 ? C_CT : p.channels;
+    constexpr int CMAX = C_CT > 0 ? C_CT : 1;
+    const int lane = threadIdx.x & 63;
+    const int tz = (p.texDepth == 1) ? 0 : pz;
+    const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
+    const float* pDy = p.dy + pidx * C;
+    const bool zt = inside && p.zflags.empty(pz, py, px);
+
+    bool active = false, finite = true;
+    float dreg[CMAX];
+    if (inside) {
+        uint32_t dmax = 0u;
+        for (int c = 0; c < C; c++) {
+            const float d = pDy[c];
+            if (C_CT > 0) dreg[c % CMAX] = d;
+            dmax |= (uint32_t)__float_as_int(d);
+            finite = finite && (fabsf(d) < INFINITY);                       // false for inf and NaN
+        }
+        active = !(__int_as_float((int)dmax) == 0.f);
+    }
+    const uint64_t am = __ballot(active);
+    bool light = (am == 0ull);                                               // nothing to scatter in this wave
+    float2 t = make_float2(0.f, 0.f);
+    if (am == ~0ull) {                                                       // every pixel active: the uniform-wave test of k_tex_grad
+        t = zt ? make_float2(0.f, 0.f) : ((const float2*)p.uv)[pidx];
+        const int ux = __float_as_int(t.x), uy = __float_as_int(t.y);
+        bool same = (ux == __builtin_amdgcn_readfirstlane(ux)) & (uy == __builtin_amdgcn_readfirstlane(uy));
+        if (FILTER != TEX_LINEAR) {
+            const float4 d = zt ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)p.uvDA)[pidx];
+            same &= (d.x == 0.f) & (d.y == 0.f) & (d.z == 0.f) & (d.w == 0.f);
+            if (p.bias) same &= !(fabsf(p.bias[pidx]) == INFINITY);
+        }
+        light = __ballot(same) == ~0ull;
+    }
+    if (__ballot(!finite) != 0ull) light = false;
+    if (!light && lane == 0) s_heavy = 1;
+    __syncthreads();
+    const bool heavy = s_heavy != 0;
+    if (threadIdx.x == 0) p.heavy[blk] = heavy ? 1 : 0;
+    if (heavy) return;
+
+    if (am == 0ull) {                                                        // explicit zeros (texture_kernel.cu:922-971)
+        if (inside) {
+            ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
+            if (FILTER == TEX_LML) {
+                if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.gradBias) p.gradBias[pidx] = 0.f;
+            }
+        }
+        return;
+    }
+    // uniform wave (all 64 lanes active, hence inside): as in k_tex_grad, with the totals leaving as a record
+    const Quad q0 = tex_index_linear(p, t.x, t.y, tz, 0);
+    const float* pIn0 = p.tex[0];
+    const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
+    const float tw0[4] = {w000, w010, w001, w011};
+    const float sclu0 = (float)p.texW, sclv0 = (float)p.texH;
+    int* recBase = p.rec + (blk * 4 + (int)(threadIdx.x >> 6));
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            recBase[(size_t)(4 + k) * p.nrec] = __float_as_int(tw0[k]);
+            if (k > 0) recBase[(size_t)k * p.nrec] = q0.tc[k];
+        }
+    }
+    float gu = 0.f, gv = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float d = C_CT > 0 ? dreg[c % CMAX] : pDy[c];
+        const float tot = wave_sum_to_last(d);                               // valid in lane 63
+        if (lane == 63) recBase[(size_t)(kTexRecHeader + c) * p.nrec] = __float_as_int(tot);
+        float a[4];
+        fetch_quad(pIn0, q0, C, c, a);
+        const float ad = (a[3] + a[0] - a[1] - a[2]);
+        gu += d * ((a[1] - a[0]) + q0.fv * ad) * sclu0;
+        gv += d * ((a[2] - a[0]) + q0.fu * ad) * sclv0;
+    }
+    if (lane == 63) {
+        int first = q0.tc[0];
+        if (first < 0) {
+#pragma unroll
+            for (int k = 1; k < 4; k++) {
+                if (first < 0 && q0.tc[k] >= 0) {
+                    first = q0.tc[k];
+                    recBase[(size_t)4 * p.nrec] = __float_as_int(tw0[k]);
+                    recBase[(size_t)k * p.nrec] = -1;
+                }
+            }
+        }
+        recBase[0] = first;
+    }
+    ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+    if (FILTER == TEX_LML) {
+        if (p.gradBias) p.gradBias[pidx] = 0.f;
+        if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -1494,7 +1614,8 @@ static long long tex_grad_records(int N, int H, int W) { return 4ll * ((W + 15) 
 extern "C" size_t nvdr_texture_grad_scratch_bytes(int N, int H, int W, int C)
 {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    return (size_t)tex_grad_records(N, H, W) * (size_t)(kTexRecHeader + C) * 4;
+    const size_t rec = (size_t)tex_grad_records(N, H, W) * (size_t)(kTexRecHeader + C) * 4;
+    return align_up(rec, 256) + align_up((size_t)tex_grad_records(N, H, W) / 4, 256);        // records + one byte per block
 }
 
 extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_host, int L,
@@ -1549,6 +1670,23 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
         NVDR_REQUIRE(!((uintptr_t)scratch & 3), "texture_grad: scratch must be 4-byte aligned");
         p.rec = (int*)scratch; p.nrec = (int)nrec;
         NVDR_HIP_CHECK(hipMemsetAsync(scratch, 0xFF, (size_t)nrec * 4, stream));           // "no record" in every first-tap slot
+        // two-kernel pass: the blocks without real footprints first, at full occupancy (k_tex_grad_light)
+        if (!(debug_flags() & 268435456)) {
+            p.heavy = (uint8_t*)scratch + align_up((size_t)nrec * (size_t)(kTexRecHeader + C) * 4, 256);
+            ProfileScope ps("tex_grad_light", stream);
+#define NVDR_TEX_LIGHT(FILTER)                                                                                      \
+    do {                                                                                                            \
+        if (C == 1)      hipLaunchKernelGGL((k_tex_grad_light<FILTER, 1>), grid, dim3(256), 0, stream, p);          \
+        else if (C == 2) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 2>), grid, dim3(256), 0, stream, p);          \
+        else if (C == 3) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 3>), grid, dim3(256), 0, stream, p);          \
+        else if (C == 4) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 4>), grid, dim3(256), 0, stream, p);          \
+        else             hipLaunchKernelGGL((k_tex_grad_light<FILTER, 0>), grid, dim3(256), 0, stream, p);          \
+    } while (0)
+            if (filter_mode == TEX_LINEAR) NVDR_TEX_LIGHT(TEX_LINEAR);
+            else if (filter_mode == TEX_LMN) NVDR_TEX_LIGHT(TEX_LMN);
+            else NVDR_TEX_LIGHT(TEX_LML);
+            NVDR_LAUNCH_CHECK();
+        }
     }
     {
         ProfileScope ps("tex_grad", stream);
