@@ -466,6 +466,25 @@ def window_stats(host_s, evt_ms, steps):
                           "on the launch stream around the same steps"}
 
 
+def graph_replay_in_child(argv, keys, script=None):
+    """The same step replayed from ONE hipGraph (nothing on the path allocates at the C-ABI level or synchronises the host, so
+    the whole step captures): what the kernels alone take when the host's launch work is out of the way.  Measured by a child
+    process running this file's --graph path: a capture that goes wrong inside the runtime takes the process with it, and
+    the bench line must not depend on that."""
+    import subprocess
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv) + (["--graph"] if "--graph" not in argv else [])
+    if script is None:
+        cmd += ["--no-cpu-baseline", "--no-extra-configs"]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+        if p.returncode != 0:
+            return {"error": "child exited with %d: %s" % (p.returncode, p.stderr.decode(errors="replace").strip().splitlines()[-1:] or "")}
+        doc = json.loads(p.stdout.decode().strip().splitlines()[-1])
+        return {k: doc[k] for k in keys}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def extra_config(name, dev, steps, warmup, windows, with_cpu, graph_too=False):
     """One more BASELINE config measured in this process (single GPU): the block that goes under `configs`."""
     wl = WORKLOADS[name]
@@ -483,24 +502,8 @@ def extra_config(name, dev, steps, warmup, windows, with_cpu, graph_too=False):
         cpu, cpu_ref = job.cpu_baselines(4 if job.full else 16)
         block["cpu_baseline"], block["cpu_reference"] = cpu, cpu_ref
     if graph_too:
-        # the same step replayed from ONE hipGraph (nothing on the path allocates at the C-ABI level or synchronises the
-        # host, so the whole step captures): what the kernels alone take when the host's launch work is out of the way
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    job.step()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                job.step()
-            host_g, evt_g = job.timed_windows(g.replay, warmup, steps, windows)
-            ms_g, _ = window_stats(host_g, evt_g, steps)
-            block["hipgraph_replay"] = {"ms_per_step": round(ms_g, 4), "value": round(P / (ms_g * 1e-3) / 1e6, 1)}
-            del g
-        except Exception as e:  # noqa: BLE001
-            block["hipgraph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        block["hipgraph_replay"] = graph_replay_in_child(["--workload", name, "--steps", str(steps), "--warmup", str(warmup),
+                                                          "--windows", str(windows)], ("ms_per_step", "value"))
     del job
     torch.cuda.empty_cache()
     return block
@@ -514,11 +517,8 @@ def c5_standin():
     fit_texture_synth.fit(iters=10, res=512, ref_res=2048, tex_size=2048)                       # warm-up: allocations, scratch
     r = fit_texture_synth.fit(iters=200, res=512, ref_res=2048, tex_size=2048)
     r["what"] = "samples/fit_texture_synth.py: all four ops fwd+bwd + Adam per iteration, eager launching; stands in for samples/torch/earth.py"
-    try:
-        rg = fit_texture_synth.fit(iters=200, res=512, ref_res=2048, tex_size=2048, graph=True)
-        r["hipgraph_replay"] = {"iters_per_s": rg["iters_per_s"], "loss_last": rg["loss_last"]}
-    except Exception as e:  # noqa: BLE001
-        r["hipgraph_replay"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    r["hipgraph_replay"] = graph_replay_in_child(["--iters", "200", "--res", "512", "--ref-res", "2048", "--tex", "2048", "--graph"],
+                                                 ("iters_per_s", "loss_last"), script=os.path.join(ROOT, "samples", "fit_texture_synth.py"))
     return r
 
 

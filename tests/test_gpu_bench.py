@@ -67,6 +67,9 @@ def test_default_run_carries_the_other_baseline_configs():
     assert p3["g_pos_err"] <= 4e-5 * max(1.0, p3["g_pos_max"])                       # the sum of two ops' summed gradients
     assert cf["c2"]["batch"] == 16 and cf["c3"]["batch"] == 32
     assert cf["c5_standin"]["iters_per_s"] > 0 and cf["c5_standin"]["loss_last"] < cf["c5_standin"]["loss_first"]
+    # the launch-bound configs also carry the step replayed from one hipGraph (measured by a child process)
+    assert cf["c2"]["hipgraph_replay"].get("ms_per_step", 0) > 0, cf["c2"]["hipgraph_replay"]
+    assert cf["c5_standin"]["hipgraph_replay"].get("iters_per_s", 0) > 0, cf["c5_standin"]["hipgraph_replay"]
 
 
 @pytest.mark.parametrize("workload", ["ch", "c4"])
