@@ -68,6 +68,28 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
     uint16_t* s_list = (uint16_t*)(s_max + 4);              // [slots] used slots (flush)
     int bx, by, pz;
     if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
+    // A block without any triangle (its 8 x 2 occupancy flags, two thirds of the bench's blocks) has nothing to accumulate:
+    // its waves store their zeros and leave before the table is cleared and the workgroup meets at its barriers.
+    if (p.flags.f && !(p.dbg & 536870912)) {
+        const int l = threadIdx.x & 63;
+        const int tx = bx * (kFuBlockW / 8) + (l & 7), ty = by * (kFuBlockH / 8) + ((l >> 3) & 1);
+        uint8_t f = 0;
+        if (l < 16 && tx < p.flags.w && ty < p.flags.h) f = p.flags.f[((size_t)pz * p.flags.h + ty) * p.flags.w + tx];
+        if (__ballot(f != 0) == 0ull) {
+            if (WRITE_GRAST) {
+                const int x = bx * kFuBlockW + l;
+#pragma unroll
+                for (int r = 0; r < kFuRows; r++) {
+                    const int y = by * kFuBlockH + (int)(threadIdx.x >> 6) * kFuRows + r;
+                    if (y >= p.height || x >= p.width) continue;
+                    const size_t pidx = ((size_t)pz * p.height + y) * p.width + x;
+                    ((float4*)p.gradRaster)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ENABLE_DA) ((float4*)p.gradRasterDB)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            return;
+        }
+    }
     VertexTable tab{s_keys, s_vals, slots, S};
     tab.clear(threadIdx.x, kFuThreads);
     if (threadIdx.x < 4) s_max[threadIdx.x] = 0u;
