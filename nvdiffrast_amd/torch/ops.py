@@ -116,12 +116,12 @@ class _RasterOrigin:
     gradient in one pass, returns g_rast as usual -- always a correct gradient -- and leaves the position gradient here;
     rasterize's backward takes it when the tensor it receives is that g_rast, and otherwise computes the gradient from
     what it did receive, as if nothing had been prepared (the context then stops preparing: `fused_disabled`)."""
-    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "db_ptr", "db_version", "grad_db",
+    __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "rast_shape", "db_ptr", "db_version", "grad_db",
                  "interpolations", "pending", "flags")
 
     def __init__(self, pos, tri, state, rast, flags, rast_db, grad_db):
         self.pos, self.tri, self.state = pos, tri, state
-        self.rast_ptr, self.rast_version = rast.data_ptr(), rast._version
+        self.rast_ptr, self.rast_version, self.rast_shape = rast.data_ptr(), rast._version, tuple(rast.shape)
         self.db_ptr, self.db_version, self.grad_db = rast_db.data_ptr(), rast_db._version, bool(grad_db)
         self.interpolations = 0            # interpolate() calls that took this rast
         self.pending = None                # (g_rast, its data_ptr, its version, g_pos) between the two backward nodes
@@ -130,7 +130,7 @@ class _RasterOrigin:
     def flags_for(self, rast):
         """The occupancy flags, if `rast` still is what rasterize() returned (same storage, never written to since):
         the kernels that read rast then skip the tiles without any triangle (include/nvdr_hip.h `tile_flags`)."""
-        if rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version:
+        if rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version and tuple(rast.shape) == self.rast_shape:
             return self.flags
         return None
 
@@ -141,7 +141,7 @@ class _RasterOrigin:
         st = self.state
         return (_plugin.fused_backward_mode() == "auto" and not st.fused_disabled and self.pending is None
                 and self.interpolations == 1 and rast.requires_grad and self.pos.requires_grad
-                and rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version
+                and rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version and tuple(rast.shape) == self.rast_shape
                 and (rast_db is None or (rast_db.data_ptr() == self.db_ptr and rast_db._version == self.db_version))
                 and tri.data_ptr() == self.tri.data_ptr() and tri.shape == self.tri.shape
                 and attr.shape[-2] == self.pos.shape[-2])
@@ -150,20 +150,32 @@ class _RasterOrigin:
 class _ZeroTiles:
     """Carried by interpolate()'s outputs: `flags` (the rasterizer's tile occupancy) marks 8x8 tiles in which this tensor is
     zero.  Valid while the tensor is untouched (same storage, same version counter)."""
-    __slots__ = ("flags", "ptr", "version")
+    __slots__ = ("flags", "ptr", "version", "shape")
 
     def __init__(self, flags, t):
-        self.flags, self.ptr, self.version = flags, t.data_ptr(), t._version
+        self.flags, self.ptr, self.version, self.shape = flags, t.data_ptr(), t._version, tuple(t.shape[:3])
+
+    def still(self, t):
+        """`t` is the tensor this record was made for, unchanged."""
+        return t.data_ptr() == self.ptr and t._version == self.version and tuple(t.shape[:3]) == self.shape
+
+    @staticmethod
+    def records(uv, uv_da):
+        """The records behind of(uv, uv_da), for the backward pass to check against its saved tensors (which need not be
+        the same Python objects any more)."""
+        zd = getattr(uv_da, "_nvdr_zero_tiles", None) if uv_da is not None and uv_da.numel() else None
+        return getattr(uv, "_nvdr_zero_tiles", None), zd
 
     @staticmethod
     def of(uv, uv_da):
         """The flags that texture(uv, uv_da) may use: both tensors (uv_da may be absent) zero on the same empty tiles."""
         z = getattr(uv, "_nvdr_zero_tiles", None)
-        if z is None or uv.data_ptr() != z.ptr or uv._version != z.version:
+        if z is None or uv.data_ptr() != z.ptr or uv._version != z.version or tuple(uv.shape[:3]) != z.shape:
             return None
         if uv_da is not None and uv_da.numel():
             zd = getattr(uv_da, "_nvdr_zero_tiles", None)
-            if zd is None or zd.flags is not z.flags or uv_da.data_ptr() != zd.ptr or uv_da._version != zd.version:
+            if (zd is None or zd.flags is not z.flags or uv_da.data_ptr() != zd.ptr or uv_da._version != zd.version
+                    or tuple(uv_da.shape[:3]) != zd.shape):
                 return None
         return z.flags
 
@@ -280,6 +292,7 @@ class _TextureOp:
     def forward(filter_mode, boundary, tex, uv, uv_da, mip_level_bias, mip_wrapper, *mip_stack):
         f = _FILTER_MODES[filter_mode]
         zf = None if boundary == _BOUNDARY_MODES["cube"] else _ZeroTiles.of(uv, uv_da)      # tiles of known-zero uv / uv_da
+        zrec = _ZeroTiles.records(uv, uv_da) if zf is not None else None
         if filter_mode in _MIPMAPPED:
             # absent optional tensors travel as empty tensors, an absent wrapper as an empty one (ops.py:301-307)
             placeholder = torch.tensor([])
@@ -291,14 +304,15 @@ class _TextureOp:
         else:
             out = _plugin.texture_fwd(tex, uv, f, boundary, tile_flags=zf)
             keep = (tex, uv)
-        return out, keep, (filter_mode, f, boundary, mip_wrapper, len(mip_stack), zf)
+        return out, keep, (filter_mode, f, boundary, mip_wrapper, len(mip_stack), zf, zrec)
 
     @staticmethod
     def backward(state, saved, d_out):
-        filter_mode, f, boundary, mip_wrapper, n_custom, zf = state
+        filter_mode, f, boundary, mip_wrapper, n_custom, zf, zrec = state
         g_uv = g_uv_da = g_bias = None
         g_levels = (None,) * n_custom
-        if zf is not None and _ZeroTiles.of(saved[1], saved[2] if filter_mode in _MIPMAPPED else None) is not zf:
+        if zf is not None and not (zrec[0].still(saved[1])
+                                   and (zrec[1] is None or filter_mode not in _MIPMAPPED or zrec[1].still(saved[2]))):
             zf = None                                         # uv / uv_da were written to since the forward pass
         if filter_mode in _MIPMAPPED:
             tex, uv, uv_da, bias = saved[:4]

@@ -162,3 +162,40 @@ def test_texture_takes_uv_of_empty_tiles_as_zero_only_while_it_is(dr, oracle, fm
     want2 = oracle.texture(tex_np, uv2, uvdao if mip else None, **kw)
     assert np.abs(want2 - want).max() > 1e-3
     within("zero tiles dropped: texture", col2.detach().cpu().numpy(), want2, ATOL)
+
+
+def test_views_of_the_rasterizers_outputs_are_ordinary_tensors(dr, oracle):
+    """A view shares storage and version counter with the tensor rasterize() / interpolate() returned, but not its shape:
+    slices and reshapes of rast and uv go through the consumers like any tensor (no flags, no fused gradient, no error)."""
+    b = m10k_batch(3, seed=77, nx=20, ny=12)
+    V = b["pos"].shape[1]
+    rng = np.random.default_rng(2)
+    uvattr = rng.uniform(0, 1, size=(V, 2)).astype(np.float32)
+    tex = rng.uniform(0, 1, size=(1, 64, 64, 3)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    t_pos = _t(b["pos"]).requires_grad_(True)
+    t_tri, t_uv, t_tex = _t(b["tri"]), _t(uvattr), _t(tex)
+    rast, _ = dr.rasterize(ctx, t_pos, t_tri, (64, 128))
+    origin = rast._nvdr_origin
+    first = rast[:1]                                               # same data_ptr, same version
+    assert origin.flags_for(first) is None and origin.flags_for(rast.view(6, 32, 128, 4)) is None
+    ro, _ = oracle.rasterize(b["pos"], b["tri"], (64, 128))
+    uv1, _ = dr.interpolate(t_uv, first, t_tri)
+    want, _ = oracle.interpolate(uvattr, ro[:1], b["tri"])
+    within("view of rast: interpolate", uv1.detach().cpu().numpy(), want, ATOL)
+    halves, _ = dr.interpolate(t_uv, rast.view(6, 32, 128, 4), t_tri)
+    want_all, _ = oracle.interpolate(uvattr, ro, b["tri"])
+    within("reshaped rast: interpolate", halves.detach().cpu().numpy().reshape(3, 64, 128, 2), want_all, ATOL)
+    # a slice of interpolate's output carries no zero-tile record either
+    uv, _ = dr.interpolate(t_uv, rast, t_tri)
+    col = dr.texture(t_tex, uv[:2], filter_mode="linear")
+    within("view of uv: texture", col.detach().cpu().numpy(), oracle.texture(tex, uv[:2].detach().cpu().numpy(), filter_mode="linear"), ATOL)
+    # and the sliced graph differentiates (two-kernel path: the slice is not the rasterizer's own tensor)
+    before = _plugin_counts()
+    uv1.sum().backward()
+    assert _plugin_counts()["used"] == before["used"] and t_pos.grad is not None and bool(torch.isfinite(t_pos.grad).all())
+
+
+def _plugin_counts():
+    from nvdiffrast_amd.torch import _plugin
+    return dict(_plugin.fused_backward_count())
