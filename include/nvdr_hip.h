@@ -94,10 +94,14 @@ size_t nvdr_rasterize_pool_peak_offset(int N, int max_tri, int H, int W, long lo
  * [N,Hpad,Wpad] u32 or NULL (NULL = no peel test, i.e. peeling_idx <= 0).  depth_out:
  * [N,Hpad,Wpad] u32 or NULL (only a DepthPeeler needs it).  Hpad/Wpad = H/W rounded up
  * to 8.  out, out_db: [N,H,W,4] f32. */
-/* tile_flags (optional output, NULL = none): [N][ceil(H/8)][ceil(W/8)] bytes, 1 = some pixel of that 8x8-pixel tile of
- * `out` shows a triangle, 0 = the whole tile is background.  The entry points below that READ a rast tensor take the
- * same array as an optional input (`tile_flags`, NULL = none) and then skip the rast / rast_db bytes of empty tiles --
- * legal only while that rast tensor is exactly what this call wrote (the operator layer checks identity and version). */
+/* tile_flags (optional output, NULL = none): a buffer of nvdr_tile_flags_bytes(N, H, W) bytes.  First [N][ceil(H/8)]
+ * [ceil(W/8)] bytes, 1 = some pixel of that 8x8-pixel tile of `out` shows a triangle, 0 = the whole tile is background;
+ * then, 16-byte aligned and only for images of at most 65536 bins of 64x64 pixels, a work order for the consuming kernels:
+ * the bins with a covered tile first, then the others, as int32 bin numbers, and their count (csrc/nvdr_device.hpp
+ * TileFlags).  The entry points below that READ a rast tensor take the same buffer as an optional input (`tile_flags`,
+ * NULL = none); they then skip the rast / rast_db bytes of empty tiles and may walk the image in that order -- legal only
+ * while that rast tensor is exactly what this call wrote (the operator layer checks identity, shape and version). */
+size_t nvdr_tile_flags_bytes(int N, int H, int W);
 int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges,
                        int instance_mode, int N, int V, int T, int max_tri, int H, int W,
                        const uint32_t* peel_depth, uint32_t* depth_out,

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p, int 
 {
     __shared__ int s_total, s_base;
     int bx, by, pz;
-    if (!decode_block(gx, gy, p.n, bx, by, pz)) return;
+    if (p.flags.order ? !decode_block_ordered(p.flags, gx, gy, kAaBlockW, kAaBlockH, bx, by, pz)
+                      : !decode_block(gx, gy, p.n, bx, by, pz)) return;
     if (threadIdx.x == 0) s_total = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -483,7 +484,7 @@ extern "C" int nvdr_antialias_fwd(const float* color, const float* rast, const f
     AAParams p;
     int rc = fill_aa(p, "antialias_fwd", color, rast, pos, tri, instance_mode, N, V, T, H, W, C);
     if (rc) return rc;
-    p.flags = TileFlags{(debug_flags() & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
+    p.flags = tile_flags_view((debug_flags() & 33554432) ? nullptr : tile_flags, N, H, W, !(debug_flags() & 134217728));
     NVDR_REQUIRE(hash && out && work, "antialias_fwd: null pointer");
     NVDR_REQUIRE(!((uintptr_t)work & 15), "work_buffer internal tensor not aligned to int4");
     NVDR_REQUIRE(!((uintptr_t)hash & 15), "topology_hash internal tensor not aligned to int4");
@@ -501,7 +502,7 @@ extern "C" int nvdr_antialias_fwd(const float* color, const float* rast, const f
     {
         ProfileScope ps("aa_discontinuity", stream);
         const int gx = (W + kAaBlockW - 1) / kAaBlockW, gy = (H + kAaBlockH - 1) / kAaBlockH;
-        const long long blocks = (long long)gx * gy * N;
+        const long long blocks = p.flags.order ? tile_flags_ordered_grid(p.flags, (64 / kAaBlockW) * (64 / kAaBlockH)) : (long long)gx * gy * N;   // (nvdr_device.hpp TileFlags)
         hipLaunchKernelGGL(k_aa_discontinuity, dim3((unsigned)(((blocks + 7) / 8) * 8)), dim3(256), 0, stream, p, gx, gy);
     }
     NVDR_LAUNCH_CHECK();

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
     uint32_t* s_max = s_keys + slots;                       // [0] attribute max, [1] used slots, [2] position max
     uint16_t* s_list = (uint16_t*)(s_max + 4);              // [slots] used slots (flush)
     int bx, by, pz;
-    if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
+    if (p.flags.order ? !decode_block_ordered(p.flags, gx, gy, kFuBlockW, kFuBlockH, bx, by, pz)
+                      : !decode_block(gx, gy, p.depth, bx, by, pz)) return;
     // A block without any triangle (its 8 x 2 occupancy flags, two thirds of the bench's blocks) has nothing to accumulate:
     // its waves store their zeros and leave before the table is cleared and the workgroup meets at its barriers.
     if (p.flags.f && !(p.dbg & 536870912)) {
@@ -349,11 +350,12 @@ extern "C" int nvdr_interpolate_rasterize_grad(const float* attr, const float* r
     p.attrBC = (attr_instance && attr_n == 1) ? 1 : 0;
     p.posInstance = pos_instance ? 1 : 0;
     p.dbg = debug_flags();
-    p.flags = TileFlags{(p.dbg & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
+    p.flags = tile_flags_view((p.dbg & 33554432) ? nullptr : tile_flags, N, H, W, !(p.dbg & 134217728));
     p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
     p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
     const int gx = (W + kFuBlockW - 1) / kFuBlockW, gy = (H + kFuBlockH - 1) / kFuBlockH;
-    const long long total = (long long)gx * gy * N;
+    // with a work order behind the flags the launch walks the order's bins, four blocks each (nvdr_device.hpp TileFlags)
+    const long long total = p.flags.order ? tile_flags_ordered_grid(p.flags, (64 / kFuBlockW) * (64 / kFuBlockH)) : (long long)gx * gy * N;
     NVDR_REQUIRE(total < (1ll << 30), "interpolate_rasterize_grad: too many pixel blocks");
     dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kFuThreads);
     // LDS vertex table: as many power-of-two slots as fit in 32 KiB (four 8-wave workgroups per CU), at most 512;

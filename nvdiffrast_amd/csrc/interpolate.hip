@@ -153,7 +153,8 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
     uint32_t* s_max = s_keys + slots;                       // [0] block max, [1] number of used slots
     uint16_t* s_list = (uint16_t*)(s_max + 4);              // [slots] used slots (flush)
     int bx, by, pz;
-    if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
+    if (p.flags.order ? !decode_block_ordered(p.flags, gx, gy, kIpBlockW, kIpBlockH, bx, by, pz)
+                      : !decode_block(gx, gy, p.depth, bx, by, pz)) return;
     VertexTable tab{s_keys, s_vals, slots, A};
     tab.clear(threadIdx.x, kIpThreads);
     if (threadIdx.x == 0) { s_max[0] = 0u; s_max[1] = 0u; }
@@ -344,7 +345,7 @@ static int fill_params(InterpParams& p, const float* attr, const float* rast, co
     if (attr_instance && attr_n == 1) p.attrBC = 1;
     p.numDiffAttr = 0;
     p.dbg = debug_flags();
-    p.flags = TileFlags{(p.dbg & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
+    p.flags = tile_flags_view((p.dbg & 33554432) ? nullptr : tile_flags, N, H, W, !(p.dbg & 134217728));
     p.widthShift = (W & (W - 1)) == 0 ? __builtin_ctz((unsigned)W) : -1;
     if (enable_da) {
         if (diff_all) { p.numDiffAttr = A; p.diff_attrs_all = 1; }
@@ -426,7 +427,7 @@ extern "C" int nvdr_interpolate_grad(const float* attr, const float* rast, const
     p.dy = dy; p.dda = enable_da ? dda : nullptr;
     p.gradAttr = g_attr; p.gradRaster = g_rast; p.gradRasterDB = enable_da ? g_rast_db : nullptr;
     const int gx = (W + kIpBlockW - 1) / kIpBlockW, gy = (H + kIpBlockH - 1) / kIpBlockH;
-    const long long total = (long long)gx * gy * N;
+    const long long total = p.flags.order ? tile_flags_ordered_grid(p.flags, (64 / kIpBlockW) * (64 / kIpBlockH)) : (long long)gx * gy * N;   // (nvdr_device.hpp TileFlags)
     NVDR_REQUIRE(total < (1ll << 30), "interpolate_grad: too many pixel blocks");
     dim3 grid((unsigned)(((total + 7) / 8) * 8)), block(kIpThreads);
     // LDS vertex table: as many power-of-two slots as fit in 20 KiB (8 workgroups per CU), at most 512.

@@ -86,12 +86,72 @@ __device__ __forceinline__ float4 load_streaming(const float4* p) {
 // discontinuity pass -- get the flags from the operator layer when the rast they are given is, untouched, the tensor that
 // rasterize() returned (ops.py `_RasterOrigin`), and then do not read the 16 (32) bytes per pixel of rast (rast_db) of an
 // empty tile at all: two thirds of the tiles of the benchmark scene.  f == nullptr: no information, read everything.
+//
+// Behind the flags the same buffer holds a WORK ORDER for those kernels (written by k_flag_order at the end of the rasterizer's
+// forward pass): the image's 64x64-pixel bins, those with a covered tile first (image-major), then the others, and the number
+// of the former.  A consumer's launch walks that list instead of the image (decode_block_ordered): every XCD takes an eighth
+// of the bins with triangles, first, then an eighth of the empty ones.  Why: workgroups are dealt to the XCDs round robin
+// and in order, so with each XCD walking through its own images (decode_block) the eight are busy only while ALL of them are
+// in a covered region, and the XCD whose images show the most pixels finishes last (the benchmark scene: 929 covered blocks
+// against a mean of 736).  Measured on the fused backward pass: 193 -> 133 us.
+constexpr int kOrderBinShift = 6;                  // bins of 64 x 64 pixels (= the rasterizer's bins)
+constexpr int kOrderMaxBins  = 1 << 16;            // beyond that (e.g. 64 images of 2048^2) no order is kept
 struct TileFlags {
     const uint8_t* f; int w, h;
+    const int* order;                              // nullptr or [nBins + 1]: the bins as described above, [nBins] = bins with a covered tile
+    int binsX, binsY, nBins;
     __device__ __forceinline__ bool empty(int pz, int py, int px) const {
         return f != nullptr && f[((size_t)pz * h + (py >> 3)) * w + (px >> 3)] == 0;
     }
 };
+
+// The buffer's layout (include/nvdr_hip.h `tile_flags`): N*h*w flag bytes, padding to 16, then (nBins + 1) ints.
+__host__ __device__ inline size_t tile_flags_order_offset(int N, int H, int W)
+{
+    return ((size_t)N * (size_t)((H + 7) >> 3) * (size_t)((W + 7) >> 3) + 15) / 16 * 16;
+}
+__host__ inline long long tile_flags_bins(int N, int H, int W)
+{
+    return (long long)N * ((H + 63) >> kOrderBinShift) * ((W + 63) >> kOrderBinShift);
+}
+__host__ inline TileFlags tile_flags_view(const uint8_t* p, int N, int H, int W, bool with_order = true)
+{
+    TileFlags t{};
+    if (!p) return t;
+    t.f = p; t.w = (W + 7) >> 3; t.h = (H + 7) >> 3;
+    const long long nb = tile_flags_bins(N, H, W);
+    if (with_order && nb <= kOrderMaxBins) {
+        t.binsX = (W + 63) >> kOrderBinShift; t.binsY = (H + 63) >> kOrderBinShift; t.nBins = (int)nb;
+        t.order = (const int*)(p + tile_flags_order_offset(N, H, W));
+    }
+    return t;
+}
+// Workgroups an ordered launch needs when each covers 1/per of a bin: every XCD may get its share rounded up, twice.
+__host__ inline long long tile_flags_ordered_grid(const TileFlags& t, int per) { return 8ll * ((t.nBins + 7) / 8 + 2) * per; }
+
+// Ordered counterpart of decode_block() for workgroups of bw x bh pixels (both dividing 64): false = nothing to do.
+__device__ __forceinline__ bool decode_block_ordered(const TileFlags& t, int gx, int gy, int bw, int bh, int& bx, int& by, int& pz)
+{
+    const int sx = 64 / bw, per = sx * (64 / bh);                  // workgroups per bin
+    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    const int slot = j / per, sub = j - slot * per;
+    const int nCov = t.order[t.nBins], nEmp = t.nBins - nCov;
+    const int cc = (nCov + 7) >> 3, ec = (nEmp + 7) >> 3;
+    const int c0 = min(xcd * cc, nCov), cn = min(c0 + cc, nCov) - c0;
+    const int e0 = min(xcd * ec, nEmp), en = min(e0 + ec, nEmp) - e0;
+    int idx;
+    if (slot < cn) idx = c0 + slot;
+    else if (slot - cn < en) idx = nCov + e0 + (slot - cn);
+    else return false;
+    const int bin = __builtin_amdgcn_readfirstlane(t.order[idx]);
+    pz = bin / (t.binsX * t.binsY);
+    const int rem = bin - pz * (t.binsX * t.binsY);
+    const int binY = rem / t.binsX, binX = rem - binY * t.binsX;
+    const int sy = sub / sx;
+    bx = binX * sx + (sub - sy * sx);
+    by = binY * (64 / bh) + sy;
+    return bx < gx && by < gy;                                     // (bins at the right / bottom border reach beyond the image)
+}
 
 // ---- triangle-id <-> f32 codec (reference csrc/common/common.h:186-193) ----------
 // Identity up to 2^24; above that the id is stored as a bit-offset float so that it

@@ -68,7 +68,7 @@ void profile_end(hipStream_t s) {
 extern "C" {
 
 const char* nvdr_last_error(void) { return nvdr::g_err; }
-int nvdr_abi_version(void) { return 6; }
+int nvdr_abi_version(void) { return 7; }
 
 int nvdr_set_option(int option, int value) {
     if (option < 0 || option >= NVDR_OPT_COUNT) { nvdr::set_error("nvdr_set_option: unknown option %d", option); return NVDR_ERR_ARG; }

@@ -575,6 +575,60 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
 }
 
 // ---------------------------------------------------------------------------------
+// Work order of the kernels that consume the image (nvdr_device.hpp TileFlags): the 64x64-pixel bins with a covered
+// tile first, in image-major order, then the others; [nBins] = how many of the former.  One workgroup, every thread a
+// run of consecutive bins; runs after the last k_fine of the call (which wrote the flags).
+// ---------------------------------------------------------------------------------
+constexpr int kFlagOrderThreads = 1024;
+__global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, int* __restrict__ order)
+{
+    __shared__ int s_wave[kFlagOrderThreads / 64];
+    const int per = (t.nBins + kFlagOrderThreads - 1) / kFlagOrderThreads;         // <= 64 (kOrderMaxBins)
+    const int b0 = min((int)threadIdx.x * per, t.nBins), b1 = min(b0 + per, t.nBins);
+    const bool wide = (t.w & 7) == 0 && ((uintptr_t)t.f & 7) == 0;                       // a bin's 8 flags of one tile row are one aligned 8-byte word
+    unsigned long long mask = 0ull;                         // bit i: bin b0 + i has a covered tile
+    {
+        const int bpi = t.binsX * t.binsY;
+        int pz = b0 / bpi, rem = b0 - pz * bpi, by = rem / t.binsX, bx = rem - by * t.binsX;
+#pragma unroll 4
+        for (int b = b0; b < b1; b++) {
+            const int ty0 = by * 8, rows = min(8, t.h - ty0), tx0 = bx * 8, cols = min(8, t.w - tx0);
+            unsigned long long any = 0ull;
+            const uint8_t* row = t.f + ((size_t)pz * t.h + ty0) * t.w + tx0;
+            if (wide) {
+                // the eight loads of a bin are in flight together (rows beyond the image re-read the first one)
+                unsigned long long v[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) v[r] = *(const unsigned long long*)(row + (size_t)(r < rows ? r : 0) * t.w);
+#pragma unroll
+                for (int r = 0; r < 8; r++) any |= v[r];
+            } else {
+                for (int r = 0; r < rows; r++, row += t.w)
+                    for (int tx = 0; tx < cols; tx++) any |= row[tx];
+            }
+            if (any) mask |= 1ull << (b - b0);
+            if (++bx == t.binsX) { bx = 0; if (++by == t.binsY) { by = 0; pz++; } }
+        }
+    }
+    const int c = __popcll(mask);
+    // inclusive scan of c over the workgroup: within the wave by shuffles, across the 16 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = 0, nCov = 0;
+    for (int w = 0; w < kFlagOrderThreads / 64; w++) { const int v = s_wave[w]; if (w < wave) before += v; nCov += v; }
+    int co = before + incl - c;                             // covered bins in front of this thread's run
+    int eo = nCov + (b0 - co);                              // empty ones, behind all the covered
+    for (int b = b0; b < b1; b++) {
+        if ((mask >> (b - b0)) & 1ull) order[co++] = b; else order[eo++] = b;
+    }
+    if (threadIdx.x == 0) order[t.nBins] = nCov;
+}
+
+// ---------------------------------------------------------------------------------
 // Fine raster + pixel shader
 // ---------------------------------------------------------------------------------
 
@@ -1195,7 +1249,8 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
     __shared__ uint32_t s_max, s_used;
     __shared__ uint16_t s_list[kGradSlots];
     int bx, by, pz;
-    if (!decode_block(gx, gy, p.N, bx, by, pz)) return;
+    if (p.flags.order ? !decode_block_ordered(p.flags, gx, gy, kGradBlockW, kGradBlockH, bx, by, pz)
+                      : !decode_block(gx, gy, p.N, bx, by, pz)) return;
     VertexTable tab{s_keys, s_vals, kGradSlots, 3};
     tab.clear(threadIdx.x, kGradThreads);
     if (threadIdx.x == 0) { s_max = 0u; s_used = 0u; }
@@ -1479,7 +1534,22 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         }
         NVDR_LAUNCH_CHECK();
     }
+    if (tile_flags && !(debug_flags() & 67108864)) {
+        const TileFlags tf = tile_flags_view(tile_flags, N, H, W);
+        if (tf.order) {
+            ProfileScope ps("raster_flag_order", stream);
+            hipLaunchKernelGGL(k_flag_order, dim3(1), dim3(kFlagOrderThreads), 0, stream, tf, (int*)tf.order);
+            NVDR_LAUNCH_CHECK();
+        }
+    }
     return NVDR_OK;
+}
+
+extern "C" size_t nvdr_tile_flags_bytes(int N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    const long long nb = tile_flags_bins(N, H, W);
+    return tile_flags_order_offset(N, H, W) + (nb <= kOrderMaxBins ? (size_t)(nb + 1) * 4 : 0);
 }
 
 extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,
@@ -1498,13 +1568,13 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
     NVDR_REQUIRE(!((uintptr_t)out & 15), "out tensor not aligned to float4");
     GradParams p;
     p.pos = pos; p.tri = tri; p.out = out; p.dy = dy; p.ddb = ddb; p.grad = grad_pos;
-    p.flags = TileFlags{(debug_flags() & 33554432) ? nullptr : tile_flags, (W + 7) >> 3, (H + 7) >> 3};
+    p.flags = tile_flags_view((debug_flags() & 33554432) ? nullptr : tile_flags, N, H, W, !(debug_flags() & 134217728));
     p.instance = instance_mode ? 1 : 0; p.N = N; p.V = V; p.T = T; p.W = W; p.H = H;
     p.xs = 2.f / (float)W; p.xo = 1.f / (float)W - 1.f;
     p.ys = 2.f / (float)H; p.yo = 1.f / (float)H - 1.f;
     p.dbg = debug_flags();
     const int gx = (W + kGradBlockW - 1) / kGradBlockW, gy = (H + kGradBlockH - 1) / kGradBlockH;
-    const long long total = (long long)gx * gy * N;
+    const long long total = p.flags.order ? tile_flags_ordered_grid(p.flags, (64 / kGradBlockW) * (64 / kGradBlockH)) : (long long)gx * gy * N;   // (nvdr_device.hpp TileFlags)
     NVDR_REQUIRE(total < (1ll << 30), "rasterize_grad: too many pixel blocks");
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     {

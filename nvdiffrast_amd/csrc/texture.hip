@@ -422,20 +422,29 @@ __device__ __forceinline__ void load_texel(float* dst, const float* base, int tc
 // Pixel of this lane: a workgroup owns a 16x16 pixel block (four waves = 2x2 tiles of 8x8), blocks
 // are dealt to the XCDs in contiguous chunks.  Returns false when the whole workgroup has no block;
 // `inside` tells whether this lane's pixel exists.
-__device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, int& pz, bool& inside)
+template <bool ORDERED = true>
+__device__ __forceinline__ bool tex_pixel(const TexParams& p, int& px, int& py, int& pz, bool& inside, int* blkOut = nullptr)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // 32-bit on purpose (the host checks the block count): a 64-bit division here is ~140 scalar instructions per wave
     const int blocksPerImage = p.tilesX * p.tilesY;                           // tilesX/Y count 16x16 blocks here
-    const int total = blocksPerImage * p.n;
-    const int perXcd = (total + 7) >> 3;
-    const int j = (int)(blockIdx.x >> 3);
-    const int blk = (int)(blockIdx.x & 7) * perXcd + j;
     inside = false;
-    if (j >= perXcd || blk >= total) return false;
-    pz = blk / blocksPerImage;
-    const int rem = blk - pz * blocksPerImage;
-    const int by = rem / p.tilesX, bx = rem - by * p.tilesX;
+    int bx, by;
+    if (ORDERED && p.zflags.order) {
+        // the rasterizer's work order travels with the flags: bins with triangles first, an eighth of them per XCD
+        // (nvdr_device.hpp TileFlags)
+        if (!decode_block_ordered(p.zflags, p.tilesX, p.tilesY, 16, 16, bx, by, pz)) return false;
+    } else {
+        const int total = blocksPerImage * p.n;
+        const int perXcd = (total + 7) >> 3;
+        const int j = (int)(blockIdx.x >> 3);
+        const int blk = (int)(blockIdx.x & 7) * perXcd + j;
+        if (j >= perXcd || blk >= total) return false;
+        pz = blk / blocksPerImage;
+        const int rem = blk - pz * blocksPerImage;
+        by = rem / p.tilesX; bx = rem - by * p.tilesX;
+    }
+    if (blkOut) *blkOut = pz * blocksPerImage + by * p.tilesX + bx;          // the block's number whatever the order of the launch
     px = bx * 16 + (wave & 1) * 8 + (lane & 7);
     py = by * 16 + (wave >> 1) * 8 + (lane >> 3);
     inside = px < p.imgW && py < p.imgH;
@@ -643,12 +652,9 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     PatchTable tab{(uint32_t*)((int*)s_mem + (size_t)groups * 16 * C), (int*)s_mem, groups, C};
     uint32_t* s_max = tab.keys + groups;                                    // [0] block max, [1] number of used patches
     int* s_used = (int*)(s_max + 4);                                        // [groups] indices of the used patches (flush)
-    int px = 0, py = 0, pz = 0; bool inside;
-    if (!tex_pixel(p, px, py, pz, inside)) return;
-    if (p.heavy) {                                               // two-kernel pass: blocks that k_tex_grad_light has finished
-        const int blk = (int)(blockIdx.x & 7) * ((p.tilesX * p.tilesY * p.n + 7) >> 3) + (int)(blockIdx.x >> 3);     // as tex_pixel
-        if (!p.heavy[blk]) return;
-    }
+    int px = 0, py = 0, pz = 0, blk = 0; bool inside;
+    if (!tex_pixel(p, px, py, pz, inside, &blk)) return;
+    if (p.heavy && !p.heavy[blk]) return;                        // two-kernel pass: blocks that k_tex_grad_light has finished
     if (groups > 0 && !(p.dbg & 2048)) tab.clear(threadIdx.x, 256);
     if (threadIdx.x == 0) { s_max[0] = 0u; s_max[1] = 0u; }
     __syncthreads();
@@ -772,7 +778,6 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
         const bool toRecord = p.rec != nullptr;
         int* recBase = nullptr;
         if (toRecord) {
-            const int blk = (int)(blockIdx.x & 7) * ((p.tilesX * p.tilesY * p.n + 7) >> 3) + (int)(blockIdx.x >> 3);     // as tex_pixel
             recBase = p.rec + (blk * 4 + (int)(threadIdx.x >> 6));
             if (lane == 63) {
 #pragma unroll
@@ -1000,9 +1005,8 @@ template <int FILTER, int C_CT>
 __global__ __launch_bounds__(256, 8) void k_tex_grad_light(const TexParams p)
 {
     __shared__ int s_heavy;
-    int px = 0, py = 0, pz = 0; bool inside;
-    if (!tex_pixel(p, px, py, pz, inside)) return;
-    const int blk = (int)(blockIdx.x & 7) * ((p.tilesX * p.tilesY * p.n + 7) >> 3) + (int)(blockIdx.x >> 3);         // as tex_pixel
+    int px = 0, py = 0, pz = 0, blk = 0; bool inside;
+    if (!tex_pixel<false>(p, px, py, pz, inside, &blk)) return;      // every block costs the same here: image order (longer contiguous rows)
     if (threadIdx.x == 0) s_heavy = 0;
     __syncthreads();
     const int C = C_CT > 0 ? C_CT : p.channels;
@@ -1496,9 +1500,10 @@ static int fill_tex_params(TexParams& p, const char* who, const float* tex, cons
     return NVDR_OK;
 }
 
-static dim3 tex_grid(const TexParams& p)
+static dim3 tex_grid(const TexParams& p, bool ordered = true)
 {
-    const long long blocks = (long long)p.tilesX * p.tilesY * p.n;             // < 2^30: checked in fill_tex_params
+    const long long blocks = (ordered && p.zflags.order) ? tile_flags_ordered_grid(p.zflags, 16)   // 16 blocks of 16x16 pixels per bin (tex_pixel)
+                                                         : (long long)p.tilesX * p.tilesY * p.n;   // < 2^30: checked in fill_tex_params
     return dim3((unsigned)(((blocks + 7) / 8) * 8));
 }
 
@@ -1582,7 +1587,7 @@ extern "C" int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs_h
     if (rc) return rc;
     NVDR_REQUIRE(out, "texture_fwd: null output");
     p.out = out;
-    if (boundary_mode != TEX_B_CUBE && !(debug_flags() & 33554432)) p.zflags = TileFlags{tile_flags, (W + 7) >> 3, (H + 7) >> 3};
+    if (boundary_mode != TEX_B_CUBE && !(debug_flags() & 33554432)) p.zflags = tile_flags_view(tile_flags, N, H, W, !(debug_flags() & 134217728));
     bool vec4 = (C == 4) && !((uintptr_t)out & 15), vec2 = (C == 2) && !((uintptr_t)out & 7);
     for (int i = 0; i <= p.levelMax; i++) { vec4 = vec4 && !((uintptr_t)p.tex[i] & 15); vec2 = vec2 && !((uintptr_t)p.tex[i] & 7); }
     const dim3 grid = tex_grid(p);
@@ -1641,7 +1646,7 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
         NVDR_REQUIRE(!((uintptr_t)g_uv_da & 7), "grad_uv_da output tensor not aligned to float2");
     }
     p.dy = dy;
-    if (!cube && !(debug_flags() & 33554432)) p.zflags = TileFlags{tile_flags, (W + 7) >> 3, (H + 7) >> 3};
+    if (!cube && !(debug_flags() & 33554432)) p.zflags = tile_flags_view(tile_flags, N, H, W, !(debug_flags() & 134217728));
     p.gradTex[0] = g_tex;
     for (int i = 1; i <= p.levelMax; i++) {
         NVDR_REQUIRE(g_mip_ptrs_host && g_mip_ptrs_host[i - 1], "texture_grad: gradient buffer of mip level %d missing", i);
@@ -1674,13 +1679,14 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
         if (!(debug_flags() & 268435456)) {
             p.heavy = (uint8_t*)scratch + align_up((size_t)nrec * (size_t)(kTexRecHeader + C) * 4, 256);
             ProfileScope ps("tex_grad_light", stream);
+            const dim3 gridL = tex_grid(p, false);
 #define NVDR_TEX_LIGHT(FILTER)                                                                                      \
     do {                                                                                                            \
-        if (C == 1)      hipLaunchKernelGGL((k_tex_grad_light<FILTER, 1>), grid, dim3(256), 0, stream, p);          \
-        else if (C == 2) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 2>), grid, dim3(256), 0, stream, p);          \
-        else if (C == 3) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 3>), grid, dim3(256), 0, stream, p);          \
-        else if (C == 4) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 4>), grid, dim3(256), 0, stream, p);          \
-        else             hipLaunchKernelGGL((k_tex_grad_light<FILTER, 0>), grid, dim3(256), 0, stream, p);          \
+        if (C == 1)      hipLaunchKernelGGL((k_tex_grad_light<FILTER, 1>), gridL, dim3(256), 0, stream, p);          \
+        else if (C == 2) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 2>), gridL, dim3(256), 0, stream, p);          \
+        else if (C == 3) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 3>), gridL, dim3(256), 0, stream, p);          \
+        else if (C == 4) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 4>), gridL, dim3(256), 0, stream, p);          \
+        else             hipLaunchKernelGGL((k_tex_grad_light<FILTER, 0>), gridL, dim3(256), 0, stream, p);          \
     } while (0)
             if (filter_mode == TEX_LINEAR) NVDR_TEX_LIGHT(TEX_LINEAR);
             else if (filter_mode == TEX_LMN) NVDR_TEX_LIGHT(TEX_LMN);

@@ -271,7 +271,8 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
         out = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         out_db = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         # one byte per 8x8 tile: does any pixel show a triangle?  Consumers of `out` skip the empty tiles (include/nvdr_hip.h)
-        flags = torch.empty((depth, (height + 7) >> 3, (width + 7) >> 3), dtype=torch.uint8, device=dev)
+        # ... and, behind those, the order in which the consumers' launches walk the image (bins with triangles first)
+        flags = torch.empty((lib.nvdr_tile_flags_bytes(depth, height, width),), dtype=torch.uint8, device=dev)
         # Depth surfaces exist only while peeling (peeling_idx >= 0); layer k > 0 reads layer k-1's.
         peel_in = depth_out = None
         if peeling_idx >= 0:
@@ -314,13 +315,20 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     return out, out_db
 
 
+def tile_flags_grid(tile_flags, n, h, w):
+    """The [N, ceil(H/8), ceil(W/8)] occupancy bytes at the front of a tile_flags buffer (tests, tools)."""
+    th, tw = (h + 7) >> 3, (w + 7) >> 3
+    return tile_flags[:n * th * tw].view(n, th, tw)
+
+
 def _flags_ok(fn, tile_flags, n, h, w, dev):
-    """tile_flags (not a reference argument): None, or the uint8 [N, ceil(H/8), ceil(W/8)] tensor rasterize_fwd_cuda made for
-    exactly the rast tensor being passed."""
+    """tile_flags (not a reference argument): None, or the uint8 buffer rasterize_fwd_cuda made for exactly the rast tensor
+    being passed (include/nvdr_hip.h: occupancy bytes of its 8x8 tiles, then the consumers' work order)."""
     if tile_flags is None:
         return None
-    _require(tile_flags.dtype == torch.uint8 and tile_flags.is_contiguous() and tile_flags.device == dev
-             and tuple(tile_flags.shape) == (n, (h + 7) >> 3, (w + 7) >> 3), fn, "tile_flags do not belong to this rast tensor")
+    _require(tile_flags.dtype == torch.uint8 and tile_flags.dim() == 1 and tile_flags.is_contiguous() and tile_flags.device == dev
+             and tile_flags.numel() == _capi.load().nvdr_tile_flags_bytes(int(n), int(h), int(w)), fn,
+             "tile_flags do not belong to this rast tensor")
     return tile_flags.data_ptr()
 
 

@@ -6,6 +6,7 @@ import pytest
 import torch
 from conftest import ATOL, grad_tol, within
 
+from nvdiffrast_amd.torch import _plugin
 from nvdiffrast_amd.utils import m10k_batch, stress_triangles
 
 pytestmark = pytest.mark.gpu
@@ -42,16 +43,38 @@ def test_flags_describe_the_rast_tensor(dr, res, n, kind):
     ctx = dr.RasterizeCudaContext()
     t_pos, t_tri = _t(pos), _t(tri)
     rast, _ = dr.rasterize(ctx, t_pos, t_tri, res)
-    flags = ctx.cpp_wrapper.last_flags
-    assert flags.dtype == torch.uint8 and tuple(flags.shape) == (n, (res[0] + 7) // 8, (res[1] + 7) // 8)
+    from nvdiffrast_amd.torch import _plugin
+    buf = ctx.cpp_wrapper.last_flags
+    assert buf.dtype == torch.uint8 and buf.dim() == 1
+    flags = _plugin.tile_flags_grid(buf, n, *res)
     want = _expected_flags(rast)
     assert torch.equal(flags, want), int((flags != want).sum())
     assert 0 < int(want.sum()) < want.numel()                     # both kinds of tile occur
-    assert rast._nvdr_origin.flags_for(rast) is flags
+    assert rast._nvdr_origin.flags_for(rast) is buf
+    _check_order(buf, want, n, res)
     with dr.DepthPeeler(ctx, t_pos, t_tri, res) as peeler:
         for _ in range(2):
             r, _ = peeler.rasterize_next_layer()
-            assert torch.equal(ctx.cpp_wrapper.last_flags, _expected_flags(r))
+            want = _expected_flags(r)
+            assert torch.equal(_plugin.tile_flags_grid(ctx.cpp_wrapper.last_flags, n, *res), want)
+            _check_order(ctx.cpp_wrapper.last_flags, want, n, res)
+
+
+def _check_order(buf, tile_grid, n, res):
+    """The work order behind the flags (include/nvdr_hip.h): every 64x64-pixel bin exactly once, those with a covered tile
+    first and in image-major order, then the others, and the count of the former."""
+    th, tw = tile_grid.shape[1:]
+    by, bx = (res[0] + 63) // 64, (res[1] + 63) // 64
+    nb = n * by * bx
+    off = (n * th * tw + 15) // 16 * 16
+    assert buf.numel() == off + 4 * (nb + 1)
+    order = buf[off:].view(torch.int32).cpu().numpy()
+    pad = torch.zeros((n, by * 8, bx * 8), dtype=torch.uint8, device=tile_grid.device)
+    pad[:, :th, :tw] = tile_grid
+    cov = pad.view(n, by, 8, bx, 8).amax(dim=(2, 4)).reshape(-1).cpu().numpy().astype(bool)
+    ncov = int(cov.sum())
+    assert order[nb] == ncov
+    assert np.array_equal(order[:ncov], np.nonzero(cov)[0]) and np.array_equal(order[ncov:nb], np.nonzero(~cov)[0])
 
 
 def test_consumers_skip_empty_tiles_only_for_the_untouched_rast(dr, oracle):
@@ -70,8 +93,10 @@ def test_consumers_skip_empty_tiles_only_for_the_untouched_rast(dr, oracle):
     pos = _t(pos_np).requires_grad_(True)
     attr = _t(b["attr"]).requires_grad_(True)
     rast, rast_db = dr.rasterize(ctx, pos, tri, res)
-    flags = rast._nvdr_origin.flags_for(rast)
-    assert flags is not None and int((flags == 0).sum()) > flags.numel() // 4
+    flags = rast._nvdr_origin.flags_for(rast)                       # the buffer the consumers are handed
+    assert flags is not None
+    grid = _plugin.tile_flags_grid(flags, N, *res)
+    assert int((grid == 0).sum()) > grid.numel() // 4
     out, out_da = dr.interpolate(attr, rast, tri, rast_db=rast_db, diff_attrs="all")
     col = torch.rand((N,) + res + (3,), device="cuda")
     aa = dr.antialias(col, rast, pos, tri)
@@ -94,7 +119,7 @@ def test_consumers_skip_empty_tiles_only_for_the_untouched_rast(dr, oracle):
     assert torch.equal(a, bb)
 
     # an in-place edit: a triangle id painted into an empty tile
-    empty = torch.nonzero(flags[0] == 0)[0]
+    empty = torch.nonzero(grid[0] == 0)[0]
     ty, tx = int(empty[0]), int(empty[1])
     r2, _ = dr.rasterize(ctx, _t(pos_np), tri, res)
     assert r2._nvdr_origin.flags_for(r2) is not None
@@ -151,8 +176,7 @@ def test_texture_takes_uv_of_empty_tiles_as_zero_only_while_it_is(dr, oracle, fm
     if g_da is not None:
         within("zero tiles: g_uv_da", g_da.cpu().numpy(), g["uv_da"], grad_tol(g["uv_da"]))
 
-    flags = rast._nvdr_origin.flags
-    e = torch.nonzero(flags[1] == 0)[0]
+    e = torch.nonzero(_plugin.tile_flags_grid(rast._nvdr_origin.flags, *rast.shape[:3])[1] == 0)[0]
     ty, tx = int(e[0]), int(e[1])
 
     def paint(uv):
