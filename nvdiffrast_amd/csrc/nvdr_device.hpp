@@ -95,7 +95,9 @@ __device__ __forceinline__ float4 load_streaming(const float4* p) {
 // in a covered region, and the XCD whose images show the most pixels finishes last (the benchmark scene: 929 covered blocks
 // against a mean of 736).  Measured on the fused backward pass: 193 -> 133 us.
 constexpr int kOrderBinShift = 6;                  // bins of 64 x 64 pixels (= the rasterizer's bins)
-constexpr int kOrderMaxBins  = 1 << 16;            // beyond that (e.g. 64 images of 2048^2) no order is kept
+constexpr int kOrderMaxBins  = 1 << 16;            // beyond that (e.g. 64 images of 2048^2) no order is kept,
+constexpr int kOrderMinBins  = 2048;               // nor below this: launches of a few hundred workgroups are over before it matters,
+                                                   // and small workloads are bound by the host, where k_flag_order is one more launch
 struct TileFlags {
     const uint8_t* f; int w, h;
     const int* order;                              // nullptr or [nBins + 1]: the bins as described above, [nBins] = bins with a covered tile
@@ -110,9 +112,10 @@ __host__ __device__ inline size_t tile_flags_order_offset(int N, int H, int W)
 {
     return ((size_t)N * (size_t)((H + 7) >> 3) * (size_t)((W + 7) >> 3) + 15) / 16 * 16;
 }
-__host__ inline long long tile_flags_bins(int N, int H, int W)
+__host__ inline long long tile_flags_bins(int N, int H, int W)       // 0: no order for this size
 {
-    return (long long)N * ((H + 63) >> kOrderBinShift) * ((W + 63) >> kOrderBinShift);
+    const long long nb = (long long)N * ((H + 63) >> kOrderBinShift) * ((W + 63) >> kOrderBinShift);
+    return (nb >= kOrderMinBins && nb <= kOrderMaxBins) ? nb : 0;
 }
 __host__ inline TileFlags tile_flags_view(const uint8_t* p, int N, int H, int W, bool with_order = true)
 {
@@ -120,7 +123,7 @@ __host__ inline TileFlags tile_flags_view(const uint8_t* p, int N, int H, int W,
     if (!p) return t;
     t.f = p; t.w = (W + 7) >> 3; t.h = (H + 7) >> 3;
     const long long nb = tile_flags_bins(N, H, W);
-    if (with_order && nb <= kOrderMaxBins) {
+    if (with_order && nb > 0) {
         t.binsX = (W + 63) >> kOrderBinShift; t.binsY = (H + 63) >> kOrderBinShift; t.nBins = (int)nb;
         t.order = (const int*)(p + tile_flags_order_offset(N, H, W));
     }

@@ -1549,7 +1549,7 @@ extern "C" size_t nvdr_tile_flags_bytes(int N, int H, int W)
 {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const long long nb = tile_flags_bins(N, H, W);
-    return tile_flags_order_offset(N, H, W) + (nb <= kOrderMaxBins ? (size_t)(nb + 1) * 4 : 0);
+    return tile_flags_order_offset(N, H, W) + (nb > 0 ? (size_t)(nb + 1) * 4 : 0);
 }
 
 extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,

@@ -272,7 +272,7 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
         out_db = torch.empty((depth, height, width, 4), dtype=torch.float32, device=dev)
         # one byte per 8x8 tile: does any pixel show a triangle?  Consumers of `out` skip the empty tiles (include/nvdr_hip.h)
         # ... and, behind those, the order in which the consumers' launches walk the image (bins with triangles first)
-        flags = torch.empty((lib.nvdr_tile_flags_bytes(depth, height, width),), dtype=torch.uint8, device=dev)
+        flags = torch.empty((tile_flags_bytes(depth, height, width),), dtype=torch.uint8, device=dev)
         # Depth surfaces exist only while peeling (peeling_idx >= 0); layer k > 0 reads layer k-1's.
         peel_in = depth_out = None
         if peeling_idx >= 0:
@@ -315,6 +315,14 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     return out, out_db
 
 
+def tile_flags_bytes(n, h, w):
+    """nvdr_tile_flags_bytes(N, H, W) without the call (it is on every consumer's path; tests/test_capi_exports.py keeps the
+    two in step): occupancy bytes, padding to 16, and for 2048 .. 65536 bins of 64x64 pixels the work order (nBins + 1 ints)."""
+    flags = n * ((h + 7) >> 3) * ((w + 7) >> 3)
+    bins = n * ((h + 63) >> 6) * ((w + 63) >> 6)
+    return (flags + 15) // 16 * 16 + (4 * (bins + 1) if 2048 <= bins <= 65536 else 0)
+
+
 def tile_flags_grid(tile_flags, n, h, w):
     """The [N, ceil(H/8), ceil(W/8)] occupancy bytes at the front of a tile_flags buffer (tests, tools)."""
     th, tw = (h + 7) >> 3, (w + 7) >> 3
@@ -327,7 +335,7 @@ def _flags_ok(fn, tile_flags, n, h, w, dev):
     if tile_flags is None:
         return None
     _require(tile_flags.dtype == torch.uint8 and tile_flags.dim() == 1 and tile_flags.is_contiguous() and tile_flags.device == dev
-             and tile_flags.numel() == _capi.load().nvdr_tile_flags_bytes(int(n), int(h), int(w)), fn,
+             and tile_flags.numel() == tile_flags_bytes(int(n), int(h), int(w)), fn,
              "tile_flags do not belong to this rast tensor")
     return tile_flags.data_ptr()
 

@@ -49,6 +49,21 @@ def test_scratch_query_is_pure_host_code(lib):
     assert lib.nvdr_rasterize_scratch_bytes(0, 100, 64, 64) == 0
 
 
+def test_tile_flags_buffer_size_in_python_equals_the_librarys(lib):
+    """_plugin.tile_flags_bytes mirrors nvdr_tile_flags_bytes (the call is kept off every consumer's path): flags, padding,
+    and the work order for 2048 .. 65536 bins of 64x64 pixels."""
+    from nvdiffrast_amd.torch import _plugin
+    import random
+    rnd = random.Random(3)
+    sizes = [(1, 8, 8), (64, 512, 512), (16, 512, 512), (32, 512, 512), (32, 1024, 1024), (1, 2048, 2048), (2, 2048, 2048), (64, 2048, 2048),
+             (1, 2049, 100), (3, 100, 77), (2047, 64, 64), (2048, 64, 64), (65536, 64, 64), (65537, 64, 64), (1, 4096, 4096)]
+    sizes += [(rnd.randint(1, 80), rnd.randint(1, 2500), rnd.randint(1, 2500)) for _ in range(200)]
+    for n, h, w in sizes:
+        assert _plugin.tile_flags_bytes(n, h, w) == lib.nvdr_tile_flags_bytes(n, h, w), (n, h, w)
+    assert _plugin.tile_flags_bytes(16, 512, 512) == 16 * 64 * 64                       # BASELINE config 2: flags only
+    assert _plugin.tile_flags_bytes(64, 512, 512) == 64 * 64 * 64 + 4 * (4096 + 1)      # the headline batch: + order
+
+
 def test_bad_arguments_are_rejected_before_any_launch(lib):
     # Null pointers / empty shapes must come back as NVDR_ERR_ARG with a message, not crash.
     rc = lib.nvdr_rasterize_fwd(None, None, None, 1, 1, 3, 1, 1, 8, 8, None, None, None, 0, 0, -1, None, None, None, None)

@@ -27,7 +27,8 @@ def _expected_flags(rast):
 
 
 @pytest.mark.parametrize("res,n,kind", [((512, 512), 3, "mesh"), ((100, 77), 2, "mesh"), ((8, 2056), 1, "mesh"), ((2100, 300), 1, "mesh"),
-                                        ((256, 256), 2, "soup"), ((64, 64), 40, "mesh"), ((520, 1030), 2, "strip")])
+                                        ((256, 256), 2, "soup"), ((64, 64), 40, "mesh"), ((520, 1030), 2, "strip"),
+                                        ((520, 330), 45, "mesh"), ((64, 128), 1100, "mesh")])      # >= 2048 bins: with a work order
 def test_flags_describe_the_rast_tensor(dr, res, n, kind):
     """Every in-image tile is written exactly once -- by the bin's own workgroup, by the workgroup that clears an empty bin
     for it, by the last part of a shared bin -- and says whether the tile shows a triangle (incl. >2048 px tiled viewports,
@@ -67,6 +68,9 @@ def _check_order(buf, tile_grid, n, res):
     by, bx = (res[0] + 63) // 64, (res[1] + 63) // 64
     nb = n * by * bx
     off = (n * th * tw + 15) // 16 * 16
+    if not 2048 <= nb <= 65536:                                   # no order kept for this size (nvdr_device.hpp kOrderMinBins)
+        assert buf.numel() == off
+        return
     assert buf.numel() == off + 4 * (nb + 1)
     order = buf[off:].view(torch.int32).cpu().numpy()
     pad = torch.zeros((n, by * 8, bx * 8), dtype=torch.uint8, device=tile_grid.device)
