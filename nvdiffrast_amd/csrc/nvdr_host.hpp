@@ -34,7 +34,8 @@ struct ProfileScope {
 //   1024 / 2048  texture grad: skip slot lookups / table clear+flush (cost splits)
 //   16384 texture grad: ignore the caller's scratch (one-level reduction);  65536 / 131072  texture grad: no LDS adds /
 //         no slot lookups and no scatter at all (timing splits, tools/exp_tex_split.py)
-//   33554432 consumers ignore the tile flags;  67108864 k_fine does not produce them;  268435456 texture grad: no
+//   33554432 consumers ignore the tile flags;  67108864 k_fine does not produce them (nor the work order behind them);
+//         134217728 consumers ignore the work order (image order, decode_block);  268435456 texture grad: no
 //         k_tex_grad_light pass;  536870912 fused backward: no early exit of blocks without triangles
 //   4194304 / 8388608  k_fine shared bins: arrival counter relaxed / release-only instead of acquire-release
 int debug_flags();

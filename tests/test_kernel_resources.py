@@ -67,6 +67,27 @@ def test_interpolate_kernels_stay_within_their_budgets(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_fused_backward_and_texture_gradient_kernels_stay_within_their_budgets(tmp_path):
+    """The fused backward without pixel differentials runs at 8 waves/SIMD (64 VGPRs) without a spilled register in every
+    instantiation (the ordered decode, the early exit of empty blocks and the opaque parameter reads were all added under
+    that constraint); with differentials 6 waves/SIMD and the spills DESIGN.md 4.4 states.  The texture gradient's light
+    kernel keeps 8 workgroups per CU, the heavy one its 96 registers with no more than 20 B/lane of scratch."""
+    k = _metadata(tmp_path, "backward_fused.hip")
+    plain = {n: v for n, v in k.items() if "k_interp_raster_grad" in n and n.endswith("ELb0EEEvNS_11FusedParamsEiii")}
+    da = {n: v for n, v in k.items() if "k_interp_raster_grad" in n and n.endswith("ELb1EEEvNS_11FusedParamsEiii")}
+    assert len(plain) == 6 and len(da) == 6, sorted(k)
+    for n, (scratch, vgprs) in plain.items():
+        assert scratch == 0 and vgprs <= 64, (n, scratch, vgprs)
+    for n, (scratch, vgprs) in da.items():
+        assert scratch <= 56 and vgprs <= 80, (n, scratch, vgprs)
+    t = _metadata(tmp_path, "texture.hip")
+    light = {n: v for n, v in t.items() if "k_tex_grad_light" in n}
+    assert light and all(s == 0 and v <= 64 for s, v in light.values()), light
+    heavy = t["_ZN4nvdr10k_tex_gradILi3ELb0ELb0ELi3EEEvNS_9TexParamsEi"]          # config 3: trilinear, 2-D, three channels
+    assert heavy[0] <= 20 and heavy[1] <= 96, heavy
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_shared_bin_handoff_waits_for_its_exchanges_before_the_barrier(tmp_path):
     """a part of a shared bin publishes its keys with returning exchanges and may count itself in only when
     the old values have come back in EVERY wave.  The compiler had sunk that wait below the workgroup barrier (the
