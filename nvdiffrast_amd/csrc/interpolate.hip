@@ -38,17 +38,25 @@ __device__ __forceinline__ int diff_index(const InterpParams& p, int i)
 
 // ---- forward (interpolate.cu:15-126) ---------------------------------------------------
 
+// pixels per thread of k_interp_fwd (measured at the headline batch / config 3: 1: 81-90 / 285 us, 4: 85 / 248, 8: 99 / 274)
+constexpr int kIpFwdPixels = 4;
+
 template <int A_CT, bool ENABLE_DA>
 __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
 {
     // grid = (blocks per image, images in chunks of 32768): the image index comes from the block index; a 64-bit
     // pidx / HW per lane was more than half of this kernel's instructions.
     const unsigned HW = (unsigned)p.width * (unsigned)p.height;
-    const unsigned inImage = blockIdx.x * 256u + threadIdx.x;
     const int pz = (int)(blockIdx.y + blockIdx.z * 32768u);
-    if (inImage >= HW || pz >= p.depth) return;
-    const size_t pidx = (size_t)pz * HW + inImage;
+    if (pz >= p.depth) return;
     const int A = A_CT > 0 ? A_CT : p.numAttr;
+    // kIpFwdPixels pixels per thread, 256 apart: a quarter of the workgroups to start, and one thread's chains of dependent
+    // loads (flag -> rast -> triangle -> vertices) overlap
+#pragma unroll
+    for (int kk = 0; kk < kIpFwdPixels; kk++) {
+    const unsigned inImage = (blockIdx.x * (unsigned)kIpFwdPixels + (unsigned)kk) * 256u + threadIdx.x;
+    if (inImage >= HW) continue;
+    const size_t pidx = (size_t)pz * HW + inImage;
 
     // A tile that rasterize() found empty: zeros without reading rast (/ rast_db): two thirds of the benchmark's tiles.
     bool known_empty = false;
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
     if (valid) {
         vi0 = p.tri[triIdx * 3 + 0]; vi1 = p.tri[triIdx * 3 + 1]; vi2 = p.tri[triIdx * 3 + 2];
         if (!indices_ok(vi0, vi1, vi2, p.numVertices))
-            return;                                         // corrupt indices: leave untouched (:54-58)
+            continue;                                       // corrupt indices: leave untouched (:54-58)
     }
     float* out = p.out + pidx * A;
     float2* outDA = ENABLE_DA ? ((float2*)p.outDA) + pidx * p.numDiffAttr : nullptr;
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
         else for (int i = 0; i < A; i++) out[i] = 0.f;
         if (da4) *(float4*)outDA = make_float4(0.f, 0.f, 0.f, 0.f);
         else if (ENABLE_DA) for (int i = 0; i < p.numDiffAttr; i++) outDA[i] = make_float2(0.f, 0.f);
-        return;
+        continue;
     }
     if (p.instance_mode && !p.attrBC) { vi0 += pz * p.numVertices; vi1 += pz * p.numVertices; vi2 += pz * p.numVertices; }
     const float* a0 = p.attr + (size_t)vi0 * A;
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
             const float4 db = ((const float4*)p.rastDB)[pidx];
             const float du0 = x0.x - x2.x, dv0 = x1.x - x2.x, du1 = x0.y - x2.y, dv1 = x1.y - x2.y;
             *(float4*)outDA = make_float4(db.x * du0 + db.z * dv0, db.y * du0 + db.w * dv0, db.x * du1 + db.z * dv1, db.y * du1 + db.w * dv1);
-            return;
+            continue;
         }
     } else {
         for (int i = 0; i < A; i++) out[i] = b0 * a0[i] + b1 * a1[i] + b2 * a2[i];
     }
-    if (!ENABLE_DA) return;
+    if (!ENABLE_DA) continue;
 
     float4 db = ((const float4*)p.rastDB)[pidx];
     for (int i = 0; i < p.numDiffAttr; i++) {
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
             dsdy = db.y * dsdu + db.w * dsdv;
         }
         outDA[i] = make_float2(dsdx, dsdy);
+    }
     }
 }
 
@@ -394,7 +403,7 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
     // around the cache it leaves `rast` (read again by the backward kernels) in place.
     p.streamOut = ((size_t)N * H * W * A * sizeof(float) > ((size_t)192 << 20)) ? 1 : 0;
     NVDR_REQUIRE((long long)H * W < (1ll << 31), "interpolate_fwd: image too large");
-    dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)(N < 32768 ? N : 32768), (unsigned)((N + 32767) / 32768)), block(256);
+    dim3 grid((unsigned)(((long long)H * W + 256 * kIpFwdPixels - 1) / (256 * kIpFwdPixels)), (unsigned)(N < 32768 ? N : 32768), (unsigned)((N + 32767) / 32768)), block(256);
     const float* VECPTR = out;
     {
         ProfileScope ps(enable_da ? "interp_fwd_da" : "interp_fwd", stream);
