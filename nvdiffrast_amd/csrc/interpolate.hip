@@ -38,8 +38,9 @@ __device__ __forceinline__ int diff_index(const InterpParams& p, int i)
 
 // ---- forward (interpolate.cu:15-126) ---------------------------------------------------
 
-// pixels per thread of k_interp_fwd (measured at the headline batch / config 3: 1: 81-90 / 285 us, 4: 85 / 248, 8: 99 / 274)
-constexpr int kIpFwdPixels = 4;
+// pixels per thread of k_interp_fwd: four where the pixel differentials are written as well (config 3: 0.285 -> 0.240 ms; eight:
+// 0.274), one otherwise (headline batch: 82 us; four: 85-93; eight: 99)
+constexpr int ip_fwd_pixels(bool enable_da) { return enable_da ? 4 : 1; }
 
 template <int A_CT, bool ENABLE_DA>
 __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
@@ -50,11 +51,12 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
     const int pz = (int)(blockIdx.y + blockIdx.z * 32768u);
     if (pz >= p.depth) return;
     const int A = A_CT > 0 ? A_CT : p.numAttr;
-    // kIpFwdPixels pixels per thread, 256 apart: a quarter of the workgroups to start, and one thread's chains of dependent
-    // loads (flag -> rast -> triangle -> vertices) overlap
+    // several pixels per thread, 256 apart: fewer workgroups to start, and one thread's chains of dependent loads
+    // (flag -> rast -> triangle -> vertices) overlap
+    constexpr int kPixels = ip_fwd_pixels(ENABLE_DA);
 #pragma unroll
-    for (int kk = 0; kk < kIpFwdPixels; kk++) {
-    const unsigned inImage = (blockIdx.x * (unsigned)kIpFwdPixels + (unsigned)kk) * 256u + threadIdx.x;
+    for (int kk = 0; kk < kPixels; kk++) {
+    const unsigned inImage = (blockIdx.x * (unsigned)kPixels + (unsigned)kk) * 256u + threadIdx.x;
     if (inImage >= HW) continue;
     const size_t pidx = (size_t)pz * HW + inImage;
 
@@ -403,7 +405,8 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
     // around the cache it leaves `rast` (read again by the backward kernels) in place.
     p.streamOut = ((size_t)N * H * W * A * sizeof(float) > ((size_t)192 << 20)) ? 1 : 0;
     NVDR_REQUIRE((long long)H * W < (1ll << 31), "interpolate_fwd: image too large");
-    dim3 grid((unsigned)(((long long)H * W + 256 * kIpFwdPixels - 1) / (256 * kIpFwdPixels)), (unsigned)(N < 32768 ? N : 32768), (unsigned)((N + 32767) / 32768)), block(256);
+    const int perWg = 256 * ip_fwd_pixels(enable_da);
+    dim3 grid((unsigned)(((long long)H * W + perWg - 1) / perWg), (unsigned)(N < 32768 ? N : 32768), (unsigned)((N + 32767) / 32768)), block(256);
     const float* VECPTR = out;
     {
         ProfileScope ps(enable_da ? "interp_fwd_da" : "interp_fwd", stream);
