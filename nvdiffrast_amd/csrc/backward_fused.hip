@@ -94,13 +94,12 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
     // Both rows of a wave lie in one 8-pixel tile row (the wave's first row is even): one flag, and both rows' rast, are
     // fetched before the table is cleared -- a wave's life is a chain of dependent loads (flag -> rast -> triangle ->
     // vertices, per row), and these are the two links whose addresses need nothing but the pixel.
-    // (Not with pixel differentials: that variant has no registers for it -- 52 instead of 20 bytes of scratch.)
+    // (With pixel differentials only the flag: that variant has no registers for rast -- 52 instead of 20 bytes of scratch.)
     constexpr bool kEarlyRast = !ENABLE_DA;
     float4 rr2[kFuRows];
+    const int px0 = bx * kFuBlockW + (int)(threadIdx.x & 63), y0 = by * kFuBlockH + (int)(threadIdx.x >> 6) * kFuRows;
+    const bool tileEmpty = px0 < p.width && y0 < p.height && p.flags.empty(pz, y0, px0);
     if (kEarlyRast) {
-        const int px0 = bx * kFuBlockW + (int)(threadIdx.x & 63), y0 = by * kFuBlockH + (int)(threadIdx.x >> 6) * kFuRows;
-        const bool in0 = px0 < p.width && y0 < p.height;
-        const bool tileEmpty = in0 && p.flags.empty(pz, y0, px0);
 #pragma unroll
         for (int r = 0; r < kFuRows; r++) {
             rr2[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
         const size_t pidx = ((size_t)pz * p.height + py) * p.width + px;
         float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kEarlyRast) rr = rr2[r];
-        else if (!p.flags.empty(pz, py, px)) rr = ((const float4*)p.rast)[pidx];      // (an empty tile's rast is not read)
+        else if (!tileEmpty) rr = ((const float4*)p.rast)[pidx];                      // (an empty tile's rast is not read)
         const int triIdx = float_to_triidx(rr.w) - 1;
         if (triIdx < 0 || triIdx >= p.numTriangles) {
             if (WRITE_GRAST) {
