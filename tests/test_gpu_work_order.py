@@ -101,3 +101,54 @@ def test_separate_backward_kernels_on_an_ordered_launch(dr, raw_oracle):
     assert torch.equal(r2, g_rast)
     within("ordered vs image order: g_attr", _np(g_attr), _np(a2), 0.1 * grad_tol(ga))
     within("ordered vs image order: g_pos", _np(g_pos), _np(p2), 0.1 * grad_tol(gp))
+
+
+@pytest.mark.parametrize("case", ["nothing visible", "every bin covered"])
+def test_orders_without_a_second_part(dr, raw_oracle, case):
+    """The two degenerate orders of a 2048-bin batch: no bin with a covered tile (all geometry outside the viewport), and no bin
+    without one (one quad over the whole image): every consumer still visits every pixel exactly once."""
+    oracle = raw_oracle
+    n, res = 32, (512, 512)
+    rng = np.random.default_rng(11)
+    quad = np.array([[-1.2, -1.2, 0.1, 1], [1.2, -1.2, 0.3, 1], [1.2, 1.2, 0.5, 1], [-1.2, 1.2, 0.2, 1]], np.float32)
+    if case == "nothing visible":
+        quad[:, 0] += 5.0
+    pos_np = np.repeat(quad[None], n, 0).copy()
+    pos_np[:, :, :2] *= rng.uniform(0.95, 1.05, size=(n, 1, 1)).astype(np.float32)
+    tri_np = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    attr_np = rng.uniform(-1, 1, size=(4, 2)).astype(np.float32)
+    tex_np = rng.uniform(size=(1, 32, 32, 3)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    pos = _t(pos_np).requires_grad_(True)
+    attr = _t(attr_np).requires_grad_(True)
+    tex = _t(tex_np).requires_grad_(True)
+    tri = _t(tri_np)
+    rast, rast_db = dr.rasterize(ctx, pos, tri, res)
+    grid = _plugin.tile_flags_grid(rast._nvdr_origin.flags, n, *res)
+    assert int(grid.sum()) == (0 if case == "nothing visible" else grid.numel())
+    uv, uv_da = dr.interpolate(attr, rast, tri, rast_db=rast_db, diff_attrs="all")
+    uv.retain_grad(); uv_da.retain_grad()
+    col = dr.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear")
+    col.retain_grad()
+    aa = dr.antialias(col, rast, pos, tri)
+    dy = rng.normal(size=aa.shape).astype(np.float32)
+    aa.backward(_t(dy))
+    rh = _np(rast)
+    ro, _ = oracle.rasterize(pos_np, tri_np, res)
+    assert (rh[..., 3] != ro[..., 3]).sum() == 0
+    uvo, uvdao = oracle.interpolate(attr_np, rh, tri_np, _np(rast_db), "all")
+    within("degenerate order: uv", _np(uv), uvo, ATOL)
+    within("degenerate order: uv_da", _np(uv_da), uvdao, grad_tol(uvdao))
+    kw = dict(filter_mode="linear-mipmap-linear")
+    within("degenerate order: texture", _np(col), oracle.texture(tex_np, _np(uv), _np(uv_da), **kw), ATOL)
+    within("degenerate order: antialias", _np(aa), oracle.antialias(_np(col), rh, pos_np, tri_np), ATOL)
+    g_col, g_pos_aa = oracle.antialias_grad(_np(col), rh, pos_np, tri_np, dy)
+    within("degenerate order: g_col", _np(col.grad), g_col, grad_tol(g_col))
+    g = oracle.texture_grad(tex_np, _np(uv), _np(col.grad), _np(uv_da), **kw)
+    within("degenerate order: g_tex", _np(tex.grad), g["tex"], grad_tol(g["tex"], 2))     # eight million terms on a handful of texels
+    within("degenerate order: g_uv", _np(uv.grad), g["uv"], grad_tol(g["uv"]), frac=1e-6)
+    within("degenerate order: g_uv_da", _np(uv_da.grad), g["uv_da"], grad_tol(g["uv_da"]), frac=1e-6)
+    ga, gr, grdb = oracle.interpolate_grad(attr_np, rh, tri_np, _np(uv.grad), _np(rast_db), _np(uv_da.grad), "all")
+    within("degenerate order: g_attr", _np(attr.grad), ga, grad_tol(ga, 2))
+    gp = oracle.rasterize_grad(pos_np, tri_np, rh, gr, grdb) + g_pos_aa
+    within("degenerate order: g_pos", _np(pos.grad), gp, grad_tol(gp, 2))
