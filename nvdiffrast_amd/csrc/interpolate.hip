@@ -40,7 +40,7 @@ __device__ __forceinline__ int diff_index(const InterpParams& p, int i)
 // ---- forward (interpolate.cu:15-126) ---------------------------------------------------
 
 // pixels per thread of k_interp_fwd: four where the pixel differentials are written as well (config 3: 0.285 -> 0.240 ms; eight:
-// 0.274), one otherwise (headline batch: 82 us; four: 85-93; eight: 99)
+// 0.274), one otherwise (headline batch: 82 us; two: 92; four: 85-93; eight: 99; workgroups of 128 threads: 100)
 constexpr int ip_fwd_pixels(bool enable_da) { return enable_da ? 4 : 1; }
 
 template <int A_CT, bool ENABLE_DA>
