@@ -96,8 +96,9 @@ size_t nvdr_rasterize_pool_peak_offset(int N, int max_tri, int H, int W, long lo
  * to 8.  out, out_db: [N,H,W,4] f32. */
 /* tile_flags (optional output, NULL = none): a buffer of nvdr_tile_flags_bytes(N, H, W) bytes.  First [N][ceil(H/8)]
  * [ceil(W/8)] bytes, 1 = some pixel of that 8x8-pixel tile of `out` shows a triangle, 0 = the whole tile is background;
- * then, 16-byte aligned and only for batches of 2048 .. 65536 bins of 64x64 pixels, a work order for the consuming kernels:
- * the bins with a covered tile first, then the others, as int32 bin numbers, and their count (csrc/nvdr_device.hpp
+ * then, 16-byte aligned and only for batches of 2048 .. 65536 bins of 64x64 pixels of images up to 2048 pixels a side, a
+ * work order for the consuming kernels: the bins with a covered tile first, then the others, as int32 bin numbers, and
+ * their count; then, 8-byte aligned, what that order is built from: one byte per bin and tile row (csrc/nvdr_device.hpp
  * TileFlags).  The entry points below that READ a rast tensor take the same buffer as an optional input (`tile_flags`,
  * NULL = none); they then skip the rast / rast_db bytes of empty tiles and may walk the image in that order -- legal only
  * while that rast tensor is exactly what this call wrote (the operator layer checks identity, shape and version). */

@@ -112,8 +112,14 @@ __host__ __device__ inline size_t tile_flags_order_offset(int N, int H, int W)
 {
     return ((size_t)N * (size_t)((H + 7) >> 3) * (size_t)((W + 7) >> 3) + 15) / 16 * 16;
 }
+// ... and behind the order, 8-byte aligned, one byte per bin and tile row from k_fine (what k_flag_order reads)
+__host__ __device__ inline size_t tile_flags_rowcov_offset(size_t order_offset, long long nBins)
+{
+    return (order_offset + (size_t)(nBins + 1) * 4 + 7) / 8 * 8;
+}
 __host__ inline long long tile_flags_bins(int N, int H, int W)       // 0: no order for this size
 {
+    if (H > 2048 || W > 2048) return 0;                 // several viewports (raster.hip kMaxViewport): k_fine's bins are not the image's
     const long long nb = (long long)N * ((H + 63) >> kOrderBinShift) * ((W + 63) >> kOrderBinShift);
     return (nb >= kOrderMinBins && nb <= kOrderMaxBins) ? nb : 0;
 }

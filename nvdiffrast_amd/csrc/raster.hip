@@ -580,34 +580,23 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
 // run of consecutive bins; runs after the last k_fine of the call (which wrote the flags).
 // ---------------------------------------------------------------------------------
 constexpr int kFlagOrderThreads = 1024;
-__global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, int* __restrict__ order)
+__global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, const uint8_t* __restrict__ rowCov, int* __restrict__ order)
 {
     __shared__ int s_wave[kFlagOrderThreads / 64];
     const int per = (t.nBins + kFlagOrderThreads - 1) / kFlagOrderThreads;         // <= 64 (kOrderMaxBins)
     const int b0 = min((int)threadIdx.x * per, t.nBins), b1 = min(b0 + per, t.nBins);
-    const bool wide = (t.w & 7) == 0 && ((uintptr_t)t.f & 7) == 0;                       // a bin's 8 flags of one tile row are one aligned 8-byte word
     unsigned long long mask = 0ull;                         // bit i: bin b0 + i has a covered tile
     {
+        // k_fine left one byte per bin and tile row (FineParams::rowCov): one 8-byte word per bin; rows beyond the image were
+        // not written
         const int bpi = t.binsX * t.binsY;
-        int pz = b0 / bpi, rem = b0 - pz * bpi, by = rem / t.binsX, bx = rem - by * t.binsX;
+        int by = (b0 % bpi) / t.binsX, bx = b0 % t.binsX;
 #pragma unroll 4
         for (int b = b0; b < b1; b++) {
-            const int ty0 = by * 8, rows = min(8, t.h - ty0), tx0 = bx * 8, cols = min(8, t.w - tx0);
-            unsigned long long any = 0ull;
-            const uint8_t* row = t.f + ((size_t)pz * t.h + ty0) * t.w + tx0;
-            if (wide) {
-                // the eight loads of a bin are in flight together (rows beyond the image re-read the first one)
-                unsigned long long v[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++) v[r] = *(const unsigned long long*)(row + (size_t)(r < rows ? r : 0) * t.w);
-#pragma unroll
-                for (int r = 0; r < 8; r++) any |= v[r];
-            } else {
-                for (int r = 0; r < rows; r++, row += t.w)
-                    for (int tx = 0; tx < cols; tx++) any |= row[tx];
-            }
-            if (any) mask |= 1ull << (b - b0);
-            if (++bx == t.binsX) { bx = 0; if (++by == t.binsY) { by = 0; pz++; } }
+            const int rows = min(8, t.h - by * 8);
+            const unsigned long long v = *(const unsigned long long*)(rowCov + (size_t)b * 8) & (rows >= 8 ? ~0ull : ((1ull << (rows * 8)) - 1ull));
+            if (v) mask |= 1ull << (b - b0);
+            if (++bx == t.binsX) { bx = 0; if (++by == t.binsY) by = 0; }
         }
     }
     const int c = __popcll(mask);
@@ -639,6 +628,7 @@ struct FineParams {
     unsigned long long* splitKeys; int* splitDone;      // their merged key arrays [split][64 tiles][64 px] and arrival counters
     const int* chunkNz;                                 // per XCD chunk: bins with triangles (in the plain instantiation each also clears one empty bin)
     uint8_t* tileFlags; int tfW, tfH;                   // out, optional: per 8x8 tile of the image, 1 = some pixel shows a triangle (nvdr_device.hpp TileFlags)
+    uint8_t* rowCov;                                    // out, optional: per bin and tile row, 1 = some tile of that row of the bin is flagged (k_flag_order reads these)
     const float* pos; const int* tri;
     int instance, N, V, T, maxTri, poolBase, slots;
     int W, H, Wp, Hp;              // image size and padded surface size
@@ -828,6 +818,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (q.tileFlags && lane == 0)                      // (lane 0 = the tile's first pixel: inside the viewport here)
                 q.tileFlags[((size_t)n2 * q.tfH + ((Y + q.vp.offy) >> 3)) * q.tfW + ((X + q.vp.offx) >> 3)] = 0;
         }
+        if (q.rowCov && lane == 0) q.rowCov[((size_t)(n2 * q.binsY + by2) * q.binsX + bx2) * kBinTiles + wave / kWavesPerRow] = 0;
     };
     // Empty bins are pure stores, and in the heavy-first order they all come last: 300 MB of zeros at the headline batch
     // that nothing overlaps (the launch was store floor + the bins' compute).  In the plain instantiation each
@@ -1090,6 +1081,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int ty = bty0 + tileRow;
     const int Y = ty * 8 + ly;                  // viewport-local pixel row
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
+    uint64_t rowAny = 0ull;
 #pragma unroll 1
     for (int tt = 0; tt < kTilesPerWave; tt++) {
         const int t = tile0 + tt;
@@ -1106,6 +1098,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             // tile occupancy for the consumers of rast (TileFlags): does any pixel of this tile, inside the viewport, show a triangle?
             const bool hit = (X < p.vp.vpw) & (Y < p.vp.vph) & ((uint32_t)key != 0xFFFFFFFFu);
             const uint64_t any = __ballot(hit);
+            rowAny |= any;
             if (laneS == 0 && X < p.vp.vpw && Y < p.vp.vph)    // lane 0 = the tile's first pixel
                 p.tileFlags[((size_t)n * p.tfH + ((Y + p.vp.offy) >> 3)) * p.tfW + ((X + p.vp.offx) >> 3)] = any ? 1 : 0;
         }
@@ -1160,6 +1153,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             store_streaming((float4*)p.out_db + pidx, odb);
         }
     }
+    if (p.rowCov && laneS == 0) p.rowCov[(size_t)work * kBinTiles + tileRow] = rowAny ? 1 : 0;
     if (kPlain) {
         // (everything recomputed from the block index here: carrying the partner across the kernel cost spilled registers)
         const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1513,6 +1507,10 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.splitKeys = (unsigned long long*)(sb + L.splitKeys); fp.splitDone = (int*)(sb + L.splitDone);
         fp.chunkNz = (const int*)(sb + L.poolPeak + 16);                                        // 8 ints behind the pool-demand counter
         fp.tileFlags = (debug_flags() & 67108864) ? nullptr : tile_flags; fp.tfW = (W + 7) >> 3; fp.tfH = (H + 7) >> 3;   // (timing switch; use with 33554432)
+        {
+            const TileFlags tfv = tile_flags_view(fp.tileFlags, N, H, W);
+            fp.rowCov = (tfv.order && tcx == 1 && tcy == 1) ? tile_flags + tile_flags_rowcov_offset(tile_flags_order_offset(N, H, W), tfv.nBins) : nullptr;
+        }
         fp.peel = peel_depth; fp.depth = depth_out; fp.out = out; fp.out_db = out_db;
         fp.xs = 2.f / (float)W; fp.xo = 1.f / (float)W - 1.f;
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
@@ -1538,7 +1536,7 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         const TileFlags tf = tile_flags_view(tile_flags, N, H, W);
         if (tf.order) {
             ProfileScope ps("raster_flag_order", stream);
-            hipLaunchKernelGGL(k_flag_order, dim3(1), dim3(kFlagOrderThreads), 0, stream, tf, (int*)tf.order);
+            hipLaunchKernelGGL(k_flag_order, dim3(1), dim3(kFlagOrderThreads), 0, stream, tf, tile_flags + tile_flags_rowcov_offset(tile_flags_order_offset(N, H, W), tf.nBins), (int*)tf.order);
             NVDR_LAUNCH_CHECK();
         }
     }
@@ -1549,7 +1547,8 @@ extern "C" size_t nvdr_tile_flags_bytes(int N, int H, int W)
 {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const long long nb = tile_flags_bins(N, H, W);
-    return tile_flags_order_offset(N, H, W) + (nb > 0 ? (size_t)(nb + 1) * 4 : 0);
+    const size_t off = tile_flags_order_offset(N, H, W);
+    return nb > 0 ? tile_flags_rowcov_offset(off, nb) + (size_t)nb * 8 : off;                          // flags; order + count; k_fine's row bytes
 }
 
 extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,

@@ -317,10 +317,14 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
 
 def tile_flags_bytes(n, h, w):
     """nvdr_tile_flags_bytes(N, H, W) without the call (it is on every consumer's path; tests/test_capi_exports.py keeps the
-    two in step): occupancy bytes, padding to 16, and for 2048 .. 65536 bins of 64x64 pixels the work order (nBins + 1 ints)."""
+    two in step): occupancy bytes, padding to 16, and for 2048 .. 65536 bins of 64x64 pixels of images up to 2048 pixels a side the
+    work order (nBins + 1 ints) and what k_flag_order builds it from."""
     flags = n * ((h + 7) >> 3) * ((w + 7) >> 3)
     bins = n * ((h + 63) >> 6) * ((w + 63) >> 6)
-    return (flags + 15) // 16 * 16 + (4 * (bins + 1) if 2048 <= bins <= 65536 else 0)
+    off = (flags + 15) // 16 * 16
+    if not (2048 <= bins <= 65536 and h <= 2048 and w <= 2048):
+        return off
+    return (off + 4 * (bins + 1) + 7) // 8 * 8 + 8 * bins          # order + count, then the rasterizer's byte per bin and tile row
 
 
 def tile_flags_grid(tile_flags, n, h, w):

@@ -51,7 +51,7 @@ def test_scratch_query_is_pure_host_code(lib):
 
 def test_tile_flags_buffer_size_in_python_equals_the_librarys(lib):
     """_plugin.tile_flags_bytes mirrors nvdr_tile_flags_bytes (the call is kept off every consumer's path): flags, padding,
-    and the work order for 2048 .. 65536 bins of 64x64 pixels."""
+    and the work order for 2048 .. 65536 bins of 64x64 pixels of images up to 2048 pixels a side."""
     from nvdiffrast_amd.torch import _plugin
     import random
     rnd = random.Random(3)
@@ -61,7 +61,7 @@ def test_tile_flags_buffer_size_in_python_equals_the_librarys(lib):
     for n, h, w in sizes:
         assert _plugin.tile_flags_bytes(n, h, w) == lib.nvdr_tile_flags_bytes(n, h, w), (n, h, w)
     assert _plugin.tile_flags_bytes(16, 512, 512) == 16 * 64 * 64                       # BASELINE config 2: flags only
-    assert _plugin.tile_flags_bytes(64, 512, 512) == 64 * 64 * 64 + 4 * (4096 + 1)      # the headline batch: + order
+    assert _plugin.tile_flags_bytes(64, 512, 512) == 64 * 64 * 64 + (4 * (4096 + 1) + 4) + 8 * 4096      # the headline batch: + order (padded to 8) + row bytes
 
 
 def test_bad_arguments_are_rejected_before_any_launch(lib):

@@ -68,15 +68,20 @@ def _check_order(buf, tile_grid, n, res):
     by, bx = (res[0] + 63) // 64, (res[1] + 63) // 64
     nb = n * by * bx
     off = (n * th * tw + 15) // 16 * 16
-    if not 2048 <= nb <= 65536:                                   # no order kept for this size (nvdr_device.hpp kOrderMinBins)
+    if not 2048 <= nb <= 65536 or max(res) > 2048:                # no order kept for this size (nvdr_device.hpp kOrderMinBins)
         assert buf.numel() == off
         return
-    assert buf.numel() == off + 4 * (nb + 1)
+    rc = (off + 4 * (nb + 1) + 7) // 8 * 8                        # behind the order: the rasterizer's byte per bin and tile row
+    assert buf.numel() == rc + 8 * nb
+    rows = buf[rc:].view(nb, 8).cpu().numpy()
     order = buf[off:].view(torch.int32).cpu().numpy()
     pad = torch.zeros((n, by * 8, bx * 8), dtype=torch.uint8, device=tile_grid.device)
     pad[:, :th, :tw] = tile_grid
     cov = pad.view(n, by, 8, bx, 8).amax(dim=(2, 4)).reshape(-1).cpu().numpy().astype(bool)
     ncov = int(cov.sum())
+    want_rows = pad.view(n, by, 8, bx, 8).amax(dim=4).permute(0, 1, 3, 2).reshape(nb, 8).cpu().numpy()      # [bin][tile row]
+    inside = (np.arange(by * 8).reshape(by, 8) < th)[None, :, None, :].repeat(n, 0).repeat(bx, 2).reshape(nb, 8)
+    assert np.array_equal(rows[inside] != 0, want_rows[inside] != 0)
     assert order[nb] == ncov
     assert np.array_equal(order[:ncov], np.nonzero(cov)[0]) and np.array_equal(order[ncov:nb], np.nonzero(~cov)[0])
 
