@@ -576,8 +576,10 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
 
 // ---------------------------------------------------------------------------------
 // Work order of the kernels that consume the image (nvdr_device.hpp TileFlags): the 64x64-pixel bins with a covered
-// tile first, in image-major order, then the others; [nBins] = how many of the former.  One workgroup, every thread a
-// run of consecutive bins; runs after the last k_fine of the call (which wrote the flags).
+// tile first, in image-major order, then the others; [nBins] = how many of the former.  One workgroup (the list needs a
+// prefix sum over all bins), every thread a run of consecutive bins; runs after k_fine, whose waves -- each shades one
+// row of eight tiles of a bin -- left one byte per bin and tile row: one 8-byte word per bin here, where the flags
+// themselves are 64 bytes per bin in eight places (14 -> 7 us at the headline batch).
 // ---------------------------------------------------------------------------------
 constexpr int kFlagOrderThreads = 1024;
 __global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, const uint8_t* __restrict__ rowCov, int* __restrict__ order)
