@@ -238,9 +238,16 @@ class Job:
         self.last_rast = None
 
     def set_chunks(self, chunks):
+        self.set_chunks(chunks)
+
+    def set_chunks(self, chunks):
+        """The rank's items are rendered in this many calls (chunks exist to overlap a chunk's image all-gather with the next
+        chunk's kernels; without the gather one call is best: larger launches, and the rasterizer's work order needs 2048 bins)."""
         self.chunks = max(1, min(int(chunks), self.N))
         self.bounds = [(self.N * c // self.chunks, self.N * (c + 1) // self.chunks) for c in range(self.chunks)]
-        self.gathered = [None] * self.chunks                          # receive buffers, reused every step
+        if not hasattr(self, "_gathered"):
+            self._gathered = {}
+        self.gathered = self._gathered.setdefault(self.chunks, [None] * self.chunks)      # receive buffers, reused every step
 
     def render(self, p):
         """Forward of the op graph for the items `p` [n,V,4] -> (output image [n,H,W,C], rast)."""
@@ -656,8 +663,11 @@ def main():
     if distributed:
         ms_ng = ms_per_step
         if gather:
+            planned = job.chunks
             job.gather_on = False
+            job.set_chunks(1)                                     # (nothing to overlap: the rank's items in one call)
             host_ng, evt_ng = job.timed_windows(run, min(args.warmup, 2), args.steps, max(1, min(args.windows, 3)))
+            job.set_chunks(planned)
             job.gather_on = True
             ms_ng, _ = window_stats(host_ng, evt_ng, args.steps)
         img_bytes = N * item_bytes
