@@ -138,20 +138,28 @@ __host__ inline TileFlags tile_flags_view(const uint8_t* p, int N, int H, int W,
 // Workgroups an ordered launch needs when each covers 1/per of a bin: every XCD may get its share rounded up, twice.
 __host__ inline long long tile_flags_ordered_grid(const TileFlags& t, int per) { return 8ll * ((t.nBins + 7) / 8 + 2) * per; }
 
+// Which entry of the order the `slot`-th bin of XCD `xcd` is: an eighth of the covered bins (the first nCov entries) first,
+// then an eighth of the others; -1 beyond the XCD's share.  (Host-callable: tests/test_work_order_index.py walks it over
+// every (nBins, nCov) and checks that tile_flags_ordered_grid's launch visits every entry exactly once.)
+__host__ __device__ inline int ordered_list_index(int nBins, int nCov, int xcd, int slot)
+{
+    const int nEmp = nBins - nCov;
+    const int cc = (nCov + 7) >> 3, ec = (nEmp + 7) >> 3;
+    const int c0 = xcd * cc < nCov ? xcd * cc : nCov, cn = (c0 + cc < nCov ? c0 + cc : nCov) - c0;
+    const int e0 = xcd * ec < nEmp ? xcd * ec : nEmp, en = (e0 + ec < nEmp ? e0 + ec : nEmp) - e0;
+    if (slot < cn) return c0 + slot;
+    if (slot - cn < en) return nCov + e0 + (slot - cn);
+    return -1;
+}
+
 // Ordered counterpart of decode_block() for workgroups of bw x bh pixels (both dividing 64): false = nothing to do.
 __device__ __forceinline__ bool decode_block_ordered(const TileFlags& t, int gx, int gy, int bw, int bh, int& bx, int& by, int& pz)
 {
     const int sx = 64 / bw, per = sx * (64 / bh);                  // workgroups per bin
     const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
     const int slot = j / per, sub = j - slot * per;
-    const int nCov = t.order[t.nBins], nEmp = t.nBins - nCov;
-    const int cc = (nCov + 7) >> 3, ec = (nEmp + 7) >> 3;
-    const int c0 = min(xcd * cc, nCov), cn = min(c0 + cc, nCov) - c0;
-    const int e0 = min(xcd * ec, nEmp), en = min(e0 + ec, nEmp) - e0;
-    int idx;
-    if (slot < cn) idx = c0 + slot;
-    else if (slot - cn < en) idx = nCov + e0 + (slot - cn);
-    else return false;
+    const int idx = ordered_list_index(t.nBins, t.order[t.nBins], xcd, slot);
+    if (idx < 0) return false;
     const int bin = __builtin_amdgcn_readfirstlane(t.order[idx]);
     pz = bin / (t.binsX * t.binsY);
     const int rem = bin - pz * (t.binsX * t.binsY);
