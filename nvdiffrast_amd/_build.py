@@ -38,11 +38,33 @@ def find_hipcc():
 
 
 def build(force=False, verbose=False):
+    """One object per source file, compiled in parallel (each .hip is a self-contained translation unit: no relocatable
+    device code), then linked; objects of unchanged sources are reused unless a header changed or `force` is set."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [find_hipcc()] + HIPCC_FLAGS + sources() + ["-o", LIB_PATH]
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = find_hipcc()
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [d for d in _deps() if not d.endswith(".hip")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
+            return obj
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 

@@ -46,6 +46,17 @@ int debug_flags() {
     return v;
 }
 
+int tune_int(const char* name, int fallback) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::string, int>> seen;
+    std::lock_guard<std::mutex> l(mu);
+    for (auto& kv : seen) if (kv.first == name) return kv.second;
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : fallback;
+    seen.emplace_back(name, v);
+    return v;
+}
+
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;

@@ -39,6 +39,8 @@ struct ProfileScope {
 //         k_tex_grad_light pass;  536870912 fused backward: no early exit of blocks without triangles
 //   4194304 / 8388608  k_fine shared bins: arrival counter relaxed / release-only instead of acquire-release
 int debug_flags();
+// Development: an integer read once from the environment (tuning experiments; the product path uses the defaults).
+int tune_int(const char* name, int fallback);
 // Optional device buffer for in-kernel timestamps (development only; nvdr_debug_buffer()).
 unsigned long long* debug_buffer();
 

@@ -61,7 +61,15 @@ constexpr int kSplitPart  = 384;                         // ... of about this ma
 constexpr int kSplitMaxParts = 4;
 constexpr int kSplitsPerChunk = 32;                      // at most this many shared bins per XCD chunk of the work order
 constexpr int kHelpersPerChunk = kSplitsPerChunk * (kSplitMaxParts - 1);
+// Launches over large meshes (bins with triangle lists, below): a bin may hold tens of thousands of triangles, so it is shared
+// by many more workgroups, of about kListSplitPart triangles each, as long as the chunk's helper slots last.
+constexpr int kListSplitTris = 2048, kListSplitPart = 1024, kListSplitMaxParts = 127, kListHelpersPerChunk = 480;
+// split descriptor: parts | part << 7 | split number << 14
+constexpr int kPartBits = 7, kPartMask = (1 << kPartBits) - 1;
 constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in the pair ring)
+constexpr int kListMinTris = 32768;                      // meshes of at least this many triangles get per-bin triangle lists (k_binscan / k_binfill)
+constexpr int kListScanFactor = 8, kListScanBias = 2048; // a bin takes its list instead of scanning its slot range when range > factor * triangles + bias
+constexpr int kFillThreads = 1024, kFillSlots = kFillThreads * 4;   // k_binfill: slots per workgroup
 constexpr int kWavesPerRow = kFineWaves / kBinTiles;        // waves sharing one row of eight 8x8 tiles
 constexpr int kTilesPerWave = kBinTiles / kWavesPerRow;
 
@@ -496,6 +504,146 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Per-bin triangle lists for large meshes (the reference's bin stage, BinRaster.inl:60-170,319-377 + CoarseRaster.inl:149-218,
+// does this for every mesh: per-CTA batches of triangles compacted into 512-entry segments per bin, merged in triangle order).
+// k_fine's filter walks a bin's RANGE of triangle slots, which is short when the index order follows the surface and the
+// mesh is small, and is the whole mesh for a soup -- 256 bins x 1 M AABBs per image at 1024^2.  From kListMinTris triangles on,
+// three steps after k_setup turn the per-bin counts it already made into exact lists:
+//   k_binscan  one workgroup: which bins are better off with a list (range > kListScanFactor * triangles + kListScanBias),
+//              exclusive prefix sum of their counts = where each list starts; lists beyond the buffer's capacity stay
+//              range-scanned, so nothing can overflow and the host is not asked anything;
+//   k_binfill  a workgroup per kFillSlots slots: LDS histogram of its (triangle, bin) pairs, ONE returning global atomic per
+//              touched bin to reserve the block's stretch of that bin's list, then the slots are written -- in no particular
+//              order: visibility is an order-free minimum (k_fine), so the lists need no sorting and no merge;
+//   k_fine     reads list entries and gathers their AABBs instead of filtering.
+// ---------------------------------------------------------------------------------
+struct ListParams {
+    const uint32_t* bbox; const int* ranges; const int* poolFinal;
+    int* binCursor; int* anyList; uint32_t* binList;
+    int instance, N, T, poolBase, slots, binsX, binsY;
+    long long cap;                                  // list entries the buffer holds
+};
+
+__global__ __launch_bounds__(1024) void k_binscan(const int* __restrict__ binCount, const int* __restrict__ binHi, const int* __restrict__ binLoInv,
+                                                  const int* __restrict__ poolCount, int* __restrict__ binCursor, int* __restrict__ anyList,
+                                                  int totalBins, int binsPerImage, int N, int poolMax, long long cap, int factor, int bias)
+{
+    __shared__ long long s_wave[16];
+    const int per = (totalBins + 1023) / 1024;
+    const int b0 = min((int)threadIdx.x * per, totalBins), b1 = min(b0 + per, totalBins);
+    for (int n = threadIdx.x; n < N; n += 1024) anyList[n] = 0;
+    __syncthreads();
+    auto wants = [&](int i) -> int {                // the bin's triangle count when a list beats the range scan, else 0
+        const int c = binCount[i];
+        if (c <= 0) return 0;
+        const int hiSlot = binHi[i];
+        const int scanLo = hiSlot ? ((0x7FFFFFFF - binLoInv[i]) & ~3) : 0;
+        const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
+        const long long range = (long long)dlen + min(poolCount[i / binsPerImage], poolMax);
+        return range > (long long)factor * c + bias ? c : 0;
+    };
+    long long sum = 0;
+    for (int i = b0; i < b1; i++) sum += wants(i);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const long long v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    long long off = incl - sum;
+    for (int w = 0; w < wave; w++) off += s_wave[w];
+    for (int i = b0; i < b1; i++) {
+        const int c = wants(i);
+        int cur = -1;
+        if (c > 0 && off + c <= cap) { cur = (int)off; anyList[i / binsPerImage] = 1; }
+        if (c > 0) off += c;                            // (a list that does not fit leaves a hole: later, shorter ones may still fit)
+        binCursor[i] = cur;
+    }
+}
+
+// Wave-level increment of an LDS counter per lane's bin: the lanes of the first two distinct bins are counted with one atomic
+// each (the common case, neighbouring triangles in one bin, would otherwise be 64 serialised same-address atomics), the rest
+// on their own.  Returns the lane's rank in its bin.  Every lane of the wave must call it.
+__device__ __forceinline__ int bin_rank(int* cnt, int b, bool valid)
+{
+    const int lane = lane_id();
+    uint64_t todo = __ballot(valid);
+    int rank = 0;
+#pragma unroll 1
+    for (int it = 0; it < 2 && todo; it++) {
+        const int lead = __builtin_ctzll(todo);
+        const int b0 = __builtin_amdgcn_readlane(b, lead);
+        const uint64_t m = __ballot(valid && b == b0) & todo;
+        int base = 0;
+        if (lane == lead) base = atomicAdd(&cnt[b0], (int)__popcll(m));
+        base = __builtin_amdgcn_readlane(base, lead);
+        if ((m >> lane) & 1ull) rank = base + mask_rank(m);
+        todo &= ~m;
+    }
+    if ((todo >> lane) & 1ull) rank = atomicAdd(&cnt[b], 1);
+    return rank;
+}
+
+__global__ __launch_bounds__(kFillThreads) void k_binfill(const ListParams p, int blocksPerImage)
+{
+    __shared__ int s_cnt[1024], s_base[1024];
+    const int n = blockIdx.x / blocksPerImage, blk = blockIdx.x - n * blocksPerImage;
+    if (!p.anyList[n]) return;
+    const int nb = p.binsX * p.binsY;
+    const int direct = p.instance ? p.T : min(p.ranges[2 * n + 1], p.poolBase);
+    const int poolEnd = p.poolBase + min(p.poolFinal[n], p.slots - p.poolBase);
+    const int blockLo = blk * kFillSlots, blockHi = blockLo + kFillSlots;
+    if (blockLo >= direct && (blockHi <= p.poolBase || blockLo >= poolEnd)) return;      // no live slot in this stretch
+    for (int b = threadIdx.x; b < nb; b += kFillThreads) { s_cnt[b] = 0; s_base[b] = p.binCursor[(size_t)n * nb + b]; }   // < 0: no list for this bin
+    __syncthreads();
+    const int slot0 = blockLo + (int)threadIdx.x * 4;
+    uint32_t box[4] = {kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox};
+    if (slot0 < p.slots) {
+        const uint4 b4 = *(const uint4*)(p.bbox + (size_t)n * p.slots + slot0);
+        box[0] = b4.x; box[1] = b4.y; box[2] = b4.z; box[3] = b4.w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = slot0 + k;
+            if (!(s < direct || (s >= p.poolBase && s < poolEnd))) box[k] = kEmptyBox;
+        }
+    }
+    // One pass counts, one writes: pass 0 leaves the block's pairs per bin in s_cnt, the bins' stretches are reserved, pass 1
+    // hands out ranks again (any order will do) and stores.
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const uint32_t bx = box[k];
+            const int x0 = (int)(bx & 255u) >> 3, y0 = (int)((bx >> 8) & 255u) >> 3, x1 = (int)((bx >> 16) & 255u) >> 3, y1 = (int)(bx >> 24) >> 3;
+            const bool live = (bx & 255u) <= ((bx >> 16) & 255u);                  // kEmptyBox: txlo > txhi
+            // first bin of every lane together (wave-aggregated), further bins of large triangles on their own
+            const int bf = y0 * p.binsX + x0;
+            const bool vf = live && s_base[live ? bf : 0] >= 0;
+            const int rf = bin_rank(s_cnt, bf, vf);
+            if (pass && vf) p.binList[(size_t)s_base[bf] + rf] = (uint32_t)(slot0 + k);
+            if (live && (x1 > x0 || y1 > y0)) {
+                for (int by = y0; by <= y1; by++)
+                    for (int bxx = (by == y0 ? x0 + 1 : x0); bxx <= x1; bxx++) {
+                        const int b = by * p.binsX + bxx;
+                        if (s_base[b] < 0) continue;
+                        const int r = atomicAdd(&s_cnt[b], 1);
+                        if (pass) p.binList[(size_t)s_base[b] + r] = (uint32_t)(slot0 + k);
+                    }
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int b = threadIdx.x; b < nb; b += kFillThreads) {
+                const int c = s_cnt[b];
+                if (c > 0) s_base[b] = atomicAdd(&p.binCursor[(size_t)n * nb + b], c);
+                s_cnt[b] = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Heavy-first work order.  Work items (image, bin) are partitioned into 8 contiguous chunks,
 // one per XCD (block b of k_fine runs on XCD b % 8, so an image's bins share one L2); inside
 // its chunk each XCD visits the bins with the most triangles first, which keeps the long
@@ -508,17 +656,34 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
                                                 int* __restrict__ poolCount, int* __restrict__ poolFinal, int* __restrict__ poolPeak, int N,
                                                 int4* __restrict__ order, int totalBins,
                                                 int* __restrict__ splitInfo, int4* __restrict__ helpers, int* __restrict__ splitDone,
-                                                int splitTris, int splitPart, int* __restrict__ chunkNz, int binsX, int binsY)
+                                                int splitTris, int splitPart, int* __restrict__ chunkNz, int binsX, int binsY,
+                                                const int* __restrict__ binCursor, int maxParts, int helpersPerChunk, int* __restrict__ splitKeyBase,
+                                                int interleave, int* __restrict__ splitBin)
 {
     __shared__ int s_bucket[32];
     __shared__ int4 s_split[kSplitsPerChunk];
+    __shared__ int s_hbase[kSplitsPerChunk];
     if (threadIdx.x < kSplitsPerChunk) s_split[threadIdx.x] = make_int4(0, 0, 0, 0);
-    for (int h = threadIdx.x; h < kHelpersPerChunk; h += 1024) helpers[blockIdx.x * kHelpersPerChunk + h] = make_int4(-1, 0, 0, 0);
+    if (splitTris != 0x7FFFFFFF)
+        for (int h = threadIdx.x; h < helpersPerChunk; h += 1024) helpers[blockIdx.x * helpersPerChunk + h] = make_int4(-1, 0, 0, 0);
     const int perXcd = (totalBins + 7) >> 3;
-    const int lo = blockIdx.x * perXcd, hi = min(lo + perXcd, totalBins);
+    // The chunk's bins: a contiguous eighth of the (image-major) list -- an image's records in one L2 -- or, `interleave`, every
+    // eighth bin: launches over fewer images than XCDs, where contiguous chunks would put all of an image's triangles, however
+    // many workgroups share its bins, on one or two XCDs (a million-triangle mesh at batch 2: k_fine 1.3 -> 0.8 ms shared, all on
+    // two XCDs).  Unused slots at the end of an interleaved chunk are marked for k_fine.
+    const int lo = blockIdx.x * perXcd;
+    // j-th bin of this chunk, or -1: contiguous, or one of every eight consecutive bins -- WHICH one rotates pseudo-randomly
+    // from group to group, so that no line through the image (an edge-on mesh is one) lands on a single XCD
+    auto chunk_bin = [&](int j) -> int {
+        const int i = interleave ? 8 * j + (int)(((uint32_t)blockIdx.x + (((uint32_t)j * 0x9E3779B1u) >> 29)) & 7u) : lo + j;
+        return i < totalBins ? i : -1;
+    };
+    for (int j = threadIdx.x; j < perXcd; j += 1024) order[lo + j] = make_int4(-1, 0, 0, 0);      // (slots that stay unused: k_fine leaves)
     if (threadIdx.x < 32) s_bucket[threadIdx.x] = 0;
     __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (int j = threadIdx.x; j < perXcd; j += 1024) {
+        const int i = chunk_bin(j);
+        if (i < 0) continue;
         int c = binCount[i];
         int bk = c > 0 ? 32 - __clz(c) : 0;              // 0, 1, 2-3, 4-7, ...
         atomicAdd(&s_bucket[31 - bk], 1);                 // descending
@@ -530,7 +695,9 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         chunkNz[blockIdx.x] = s_bucket[31];               // bins with triangles in this chunk: the empty ones follow them in the order
     }
     __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+    for (int j = threadIdx.x; j < perXcd; j += 1024) {
+        const int i = chunk_bin(j);
+        if (i < 0) continue;
         int c = binCount[i];
         int bk = c > 0 ? 32 - __clz(c) : 0;
         int pos = atomicAdd(&s_bucket[31 - bk], 1);
@@ -538,6 +705,10 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         const int scanLo = hiSlot ? ((0x7FFFFFFF - binLoInv[i]) & ~3) : 0;
         const int dlen = hiSlot ? (((hiSlot + 3) & ~3) - scanLo) : 0;
         int4 ent = make_int4(i, c, scanLo, dlen);
+        if (binCursor && c > 0) {                          // the bin has a triangle list (k_binscan): where it starts, and minus its length
+            const int off = binCursor[i];
+            if (off >= 0) { ent.z = off; ent.w = -c; }       // (helper items carry no count of their own: the list's length travels in w)
+        }
         if (c == 0) {                                      // an empty bin: its coordinates, for the workgroup that clears it (k_fine)
             const int n = i / (binsX * binsY), b = i - n * (binsX * binsY), by = b / binsX;
             ent.z = (n << 10) | (by << 5) | (b - by * binsX);
@@ -546,25 +717,47 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
         // Bins with very many triangles (edge-on meshes) would each keep one workgroup busy for as long as the whole
         // launch takes: their slot range is shared by up to kSplitMaxParts workgroups (k_fine merges the parts' keys).
         // The kSplitsPerChunk heaviest bins of the chunk qualify: their position in the heavy-first order is their split number.
-        int info = 0;
-        if (c >= splitTris && pos < kSplitsPerChunk) {
-            const int parts = max(2, min(kSplitMaxParts, (c + splitPart - 1) / splitPart));
-            const int gs = blockIdx.x * kSplitsPerChunk + pos;                          // split number of this call
-            info = (gs << 8) | parts;
-            s_split[pos] = make_int4(i, info, scanLo, dlen);
-            splitDone[gs] = 0;
-        }
-        splitInfo[lo + pos] = info;
+        if (c >= splitTris && pos < kSplitsPerChunk)
+            s_split[pos] = make_int4(i, c, ent.z, ent.w);      // .y: its triangles, for now
+        splitInfo[lo + pos] = 0;
         binCount[i] = 0; binHi[i] = 0; binLoInv[i] = 0;   // this thread was the bin's only reader in this pass
     }
-    // Helper items of the shared bins, packed at the front of the chunk's helper slots (heaviest bin first).
+    // Helper items of the shared bins, packed at the front of the chunk's helper slots (heaviest bin first): the parts a bin
+    // gets are what it wants while the chunk's helper slots last (a bin left with one part is not shared); its parts' key
+    // arrays are consecutive in the exchange buffer, from splitKeyBase on.
     __syncthreads();
-    if (threadIdx.x < kSplitsPerChunk && s_split[threadIdx.x].y) {
-        int base = 0;
-        for (int q = 0; q < (int)threadIdx.x; q++) if (s_split[q].y) base += (s_split[q].y & 15) - 1;
-        const int4 e = s_split[threadIdx.x];
-        for (int k = 1; k < (e.y & 15); k++)
-            helpers[blockIdx.x * kHelpersPerChunk + base + k - 1] = make_int4(e.x, (e.y & ~0xFF) | (k << 4) | (e.y & 15), e.z, e.w);
+    if (splitTris != 0x7FFFFFFF) {                          // (uniform: launches that share no bin skip all of this)
+        __shared__ int s_kbase[kSplitsPerChunk];
+        if (threadIdx.x == 0) {
+            // triangles per part: as asked, or more when the chunk's helper slots would not last -- then every shared bin gets
+            // parts of the same size instead of the heaviest ones taking all slots (sum(ceil(c / size) - 1) < sum(c) / size <= slots)
+            long long sumC = 0;
+            for (int q = 0; q < kSplitsPerChunk; q++) sumC += s_split[q].y;
+            const int partSize = max(splitPart, (int)((sumC + helpersPerChunk - 1) / helpersPerChunk));
+            int usedH = 0, usedK = 0;
+            for (int q = 0; q < kSplitsPerChunk; q++) {
+                const int c = s_split[q].y;
+                int parts = c ? max(2, min(maxParts, (c + partSize - 1) / partSize)) : 0;
+                if (parts) parts = min(parts, 1 + helpersPerChunk - usedH);
+                if (parts < 2) { s_split[q].y = 0; continue; }
+                s_split[q].y = ((blockIdx.x * kSplitsPerChunk + q) << (2 * kPartBits)) | parts;      // split number of this call, parts
+                s_hbase[q] = usedH; s_kbase[q] = usedK;
+                usedH += parts - 1; usedK += parts;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kSplitsPerChunk) {
+            const int4 e = s_split[threadIdx.x];
+            const int gs = blockIdx.x * kSplitsPerChunk + threadIdx.x;
+            splitBin[gs] = e.y ? e.x : -1;
+            if (e.y) {
+                splitKeyBase[gs] = blockIdx.x * (helpersPerChunk + kSplitsPerChunk) + s_kbase[threadIdx.x];
+                splitDone[gs] = 0;
+                splitInfo[lo + threadIdx.x] = e.y;                      // (the bin's position in the heavy-first order is its split's)
+                for (int k = 1; k < (e.y & kPartMask); k++)
+                    helpers[blockIdx.x * helpersPerChunk + s_hbase[threadIdx.x] + k - 1] = make_int4(e.x, e.y | (k << kPartBits), e.z, e.w);
+            }
+        }
     }
     if (blockIdx.x == 0)
         for (int n = threadIdx.x; n < N; n += 1024) {
@@ -627,8 +820,11 @@ struct FineParams {
     const uint4* rec; const uint32_t* bbox; const int* poolFinal; const int* ranges;
     const int4* order;
     const int* splitInfo; const int4* helpers;          // bins shared by several workgroups (k_order)
-    unsigned long long* splitKeys; int* splitDone;      // their merged key arrays [split][64 tiles][64 px] and arrival counters
+    unsigned long long* splitKeys; int* splitDone;      // their parts' key arrays [64 tiles][64 px] and arrival counters
+    const int* splitKeyBase;                            // per split: number of its first key array
+    const int* splitBin;                                // per split: its bin (work item), -1 = unused (the shading launch of LIST launches)
     const int* chunkNz;                                 // per XCD chunk: bins with triangles (in the plain instantiation each also clears one empty bin)
+    const uint32_t* binList;                            // triangle lists of the bins that have one (k_binfill), else nullptr
     uint8_t* tileFlags; int tfW, tfH;                   // out, optional: per 8x8 tile of the image, 1 = some pixel shows a triangle (nvdr_device.hpp TileFlags)
     uint8_t* rowCov;                                    // out, optional: per bin and tile row, 1 = some tile of that row of the bin is flagged (k_flag_order reads these)
     const float* pos; const int* tri;
@@ -768,7 +964,14 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
 
 // DBG = development instrumentation (per-workgroup phase timestamps and experiment switches); the
 // production instantiation carries none of it (the kernel sits at the 64-VGPR limit of 4 workgroups/CU).
-template <bool PEEL, bool WRITE_DEPTH, bool DBG, bool SPLIT>
+// LIST = the launch may contain bins with a triangle list (large meshes); a separate instantiation, so that the others keep their
+// register budget.
+// A shared bin of a LIST launch has ONE key array in memory: its parts merge their keys into it with (non-returning) 64-bit
+// atomic minima and leave; a second launch of this kernel, SHADE, one workgroup per shared bin, reads the array, leaves it
+// as it found it (all ones) and shades.  The kernel boundary is the hand-off -- no arrival counter, no fence, no waiting for
+// exchanges, which is what made many small parts expensive in the one-launch scheme of the small launches (k_fine over a
+// million-triangle mesh, parts of 1024 triangles: 2.0 ms with the exchange).
+template <bool PEEL, bool WRITE_DEPTH, bool DBG, bool SPLIT, bool LIST = false, bool SHADE = false>
 __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fine(const FineParams p)
 {
     __shared__ FineShared sh;
@@ -781,20 +984,27 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     // triangles): the first kHelpersPerChunk block numbers of every XCD are helper slots -- extra workgroups for the
     // heaviest bins, each taking a part of the bin's slot range (they start together with those bins).
     const int perXcd = (p.totalBins + 7) >> 3;
-    const int xcd = (int)(blockIdx.x & 7), jj = (int)(blockIdx.x >> 3) - (SPLIT ? kHelpersPerChunk : 0);
+    constexpr int kHelpers = LIST ? kListHelpersPerChunk : kHelpersPerChunk;
+    const int xcd = (int)(blockIdx.x & 7), jj = (int)(blockIdx.x >> 3) - (SPLIT ? kHelpers : 0);
     int4 it4;
     int item = -1, part = 0, parts = 1, split = 0;
-    if (SPLIT && jj < 0) {
-        it4 = p.helpers[xcd * kHelpersPerChunk + jj + kHelpersPerChunk];
+    if (SHADE) {
+        split = (int)blockIdx.x;
+        const int b = p.splitBin[split];
+        if (b < 0) return;
+        it4 = make_int4(b, 0, 0, 0); parts = 2;
+    } else if (SPLIT && jj < 0) {
+        it4 = p.helpers[xcd * kHelpers + jj + kHelpers];
         if (it4.x < 0) return;
-        split = it4.y >> 8; part = (it4.y >> 4) & 15; parts = it4.y & 15;
+        split = it4.y >> (2 * kPartBits); part = (it4.y >> kPartBits) & kPartMask; parts = it4.y & kPartMask;
     } else {
         item = xcd * perXcd + jj;
-        if (jj >= perXcd || item >= p.totalBins) return;
+        if (jj >= perXcd || (!SPLIT && item >= p.totalBins)) return;
         it4 = p.order[item];
+        if (it4.x < 0) return;                               // (unused slot at the end of a chunk, k_order)
         if (SPLIT) {
             const int info = p.splitInfo[item];
-            if (info) { split = info >> 8; parts = info & 15; }
+            if (info) { split = info >> (2 * kPartBits); parts = info & kPartMask; }
         }
     }
     const int binsPerImage = p.binsX * p.binsY;
@@ -826,7 +1036,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     // that nothing overlaps (the launch was store floor + the bins' compute).  In the plain instantiation each
     // bin WITH triangles therefore also clears one empty bin of its chunk after shading its own -- the stores go out while
     // other workgroups of the CU rasterise -- and the empty bin's own workgroup leaves at once.
-    constexpr bool kPlain = !PEEL && !WRITE_DEPTH && !DBG && !SPLIT;
+    constexpr bool kPlain = !PEEL && !WRITE_DEPTH && !DBG && !SPLIT && !LIST;
     const int work = it4.x;
     if (kPlain && it4.y == 0) {
         const int nz = p.chunkNz[xcd];
@@ -844,7 +1054,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int bin = work - n * binsPerImage;
     const int binY = bin / p.binsX, binX = bin - binY * p.binsX;
     const int btx0 = binX * kBinTiles, bty0 = binY * kBinTiles;
-    const int binTris = (SPLIT && parts > 1) ? 0x7FFFFFFF : it4.y;   // triangles whose AABB touches this bin (a part does not know its share: it scans its whole range)
+    const int binTris = SHADE ? 0 : (SPLIT && parts > 1) ? 0x7FFFFFFF : it4.y;   // triangles whose AABB touches this bin (a part does not know its share: it scans its whole range)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -867,8 +1077,11 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         // recorded the smallest and largest slot that touches the bin; meshes are spatially coherent
         // in index order, so this is a small part of the image's triangles), [dlen, dlen + pool) =
         // the clipper's pool slots.  Four consecutive slots per lane per step.
+        // A bin with a triangle list (large meshes, k_binscan / k_binfill): it4.z = where the list starts, it4.w = minus its
+        // length; the "index space" is then the list itself and nothing is filtered.
+        const bool listMode = LIST && it4.w < 0;
         const int scanLo = it4.z, dlen = it4.w;
-        int total = dlen + pool, scanBeg = 0;
+        int total = listMode ? -it4.w : dlen + pool, scanBeg = 0;
         if (SPLIT && parts > 1) {                   // this workgroup's part of the index space (multiples of 4 slots)
             const int per = ((total + parts - 1) / parts + 3) & ~3;
             scanBeg = min(part * per, total);
@@ -878,7 +1091,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         const uint4*    grec = p.rec + (size_t)n * p.slots * 4;
 
         constexpr int kStep = kFineThreads * 4;     // slots per workgroup step
-        int scan = scanBeg + wave * 256;            // this wave's position in the scanned index space
+        int scan = scanBeg + (listMode ? 0 : wave * 256);   // this wave's position in the scanned index space (list: the workgroup's)
         int sub = 0, skip = 0;                      // resume point inside the current group of 4x64 slots
         bool done = (scan >= total);
         int found = 0;                              // list entries consumed by earlier rounds
@@ -908,9 +1121,21 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         for (;;) {
             // (re)loaded at the start of every pass instead of being carried over the raster stage: four registers
             // less there, where the kernel sits at its 64-VGPR budget
-            uint4 cur = done ? make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox) : load_boxes(scan);
+            uint4 cur = (done || listMode) ? make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox) : load_boxes(scan);
+            if (listMode && !done) {
+                // ---- the next kListCap entries of the bin's list, with their AABBs ----------
+                const int take = min(kListCap, total - scan);
+                if ((int)threadIdx.x < take) {
+                    const uint32_t slot = p.binList[(size_t)(uint32_t)scanLo + scan + threadIdx.x];
+                    sh.slot[threadIdx.x] = slot;
+                    sh.box[threadIdx.x] = gbox[slot];
+                }
+                if (threadIdx.x == 0) sh.count = take;
+                scan += take;
+                done = (scan >= total);
+            }
             // ---- filter: compact this bin's triangles into the LDS list ----------------
-            while (!done) {
+            while (!done && !listMode) {
                 if (found + sh.count >= binTris) { done = true; break; }       // every triangle of the bin is listed
                 const int nextScan = scan + kStep;
                 uint4 nxt = make_uint4(kEmptyBox, kEmptyBox, kEmptyBox, kEmptyBox);
@@ -1051,8 +1276,25 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     //      write-back (an agent-scope fence in a kernel with hundreds of MB of stores in flight costs more than the
     //      split saves: 126 -> 220 us) -- and a part knows its keys are in place when the old values have come back,
     //      which is before it counts itself in.  Nothing needs initialising: every part writes all of its keys.
-    unsigned long long* gkeys = p.splitKeys + (size_t)split * (kSplitMaxParts * 4096) + (size_t)(tileRow * kBinTiles + tile0) * 64 + laneS;
-    if (SPLIT && parts > 1) {
+    unsigned long long* gkeys = p.splitKeys + (size_t)((SPLIT && parts > 1) ? (LIST ? split : p.splitKeyBase[split]) : 0) * 4096 + (size_t)(tileRow * kBinTiles + tile0) * 64 + laneS;
+    if (LIST && SPLIT && parts > 1) {
+        if (!SHADE) {
+            // a part of a shared bin: its keys into the bin's array (untouched pixels have nothing to say), and done
+#pragma unroll
+            for (int tt = 0; tt < kTilesPerWave; tt++) {
+                const unsigned long long key = sh.key[tileRow][tile0 + tt][laneS];
+                if (key != kInit) (void)__hip_atomic_fetch_min(&gkeys[tt * 64], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // the shading launch: the merged keys, and the array back to all ones for the next call
+#pragma unroll
+        for (int tt = 0; tt < kTilesPerWave; tt++) {
+            sh.key[tileRow][tile0 + tt][laneS] = gkeys[tt * 64];           // (read again below by this same lane)
+            gkeys[tt * 64] = ~0ull;
+        }
+    }
+    if (!LIST && SPLIT && parts > 1) {
         unsigned long long seen = 0ull;
 #pragma unroll
         for (int tt = 0; tt < kTilesPerWave; tt++)
@@ -1089,9 +1331,16 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         const int t = tile0 + tt;
         const int X = (btx0 + t) * 8 + lx;
         unsigned long long key = sh.key[tileRow][t][laneS];
-        if (SPLIT)
-            for (int q = 0; q < parts; q++)                                      // (parts > 1: the last part only)
-                if (parts > 1 && q != part) key = min(key, atomicMin(&gkeys[q * 4096 + tt * 64], ~0ull));     // a read at the coherent point
+        if (!LIST && SPLIT && parts > 1) {                                       // (the last part only)
+            // the other parts' keys: agent-scope atomic LOADS -- they observe the parts' exchanges wherever those ran, like the
+            // returning atomics this loop used before, but several of them are in flight at a time (a bin shared by 64 parts reads
+            // 512 values per lane here: one dependent round trip each was the launch's critical path)
+#pragma unroll 4
+            for (int q = 0; q < parts; q++) {
+                const unsigned long long other = __hip_atomic_load(&gkeys[(q == part ? part : q) * 4096 + tt * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                key = min(key, q == part ? key : other);
+            }
+        }
         if (WRITE_DEPTH) {
             if (X < vpwPad && Y < vphPad)
                 p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
@@ -1118,25 +1367,29 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 // Perspective-correct barycentrics from the edge functions of the pixel-relative
                 // vertices (rasterize.cu:63-113), in the same cyclic form as the backward tape
                 // (raster_pixel_grad): a_k = X_i Y_j - Y_i X_j, i = k+1, j = k+2.
+                // Every multiply-add is spelled out (the sites nvcc's default -fmad contracts in the reference's expressions,
+                // as in the oracle): left to the compiler, two instantiations of this kernel may fuse different products, and
+                // on sub-pixel triangles -- a_k is a difference of nearly equal products -- that moves u, v by 2e-5.
+#pragma clang fp contract(off)
                 const float4 P[3] = {vb[vi0], vb[vi1], vb[vi2]};
-                const float fx = p.xs * (float)px + p.xo;
-                const float fy = p.ys * (float)py + p.yo;
+                const float fx = __fmaf_rn(p.xs, (float)px, p.xo);
+                const float fy = __fmaf_rn(p.ys, (float)py, p.yo);
                 float Xr[3], Yr[3], a[3], DX[3], DY[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { Xr[k] = P[k].x - fx * P[k].w; Yr[k] = P[k].y - fy * P[k].w; }
+                for (int k = 0; k < 3; k++) { Xr[k] = __fmaf_rn(-fx, P[k].w, P[k].x); Yr[k] = __fmaf_rn(-fy, P[k].w, P[k].y); }
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const int i = (k + 1) % 3, j = (k + 2) % 3;
-                    a[k] = Xr[i] * Yr[j] - Yr[i] * Xr[j];
-                    DX[k] = P[j].y * P[i].w - P[i].y * P[j].w;          // d a_k / d fx
-                    DY[k] = P[i].x * P[j].w - P[j].x * P[i].w;          // d a_k / d fy
+                    a[k] = __fmaf_rn(Xr[i], Yr[j], -(Yr[i] * Xr[j]));
+                    DX[k] = __fmaf_rn(P[j].y, P[i].w, -(P[i].y * P[j].w));          // d a_k / d fx
+                    DY[k] = __fmaf_rn(P[i].x, P[j].w, -(P[j].x * P[i].w));          // d a_k / d fy
                 }
                 // v_rcp_f32 (1 ulp) instead of IEEE division: three divisions per pixel are a sixth of
                 // this kernel's instruction count, and these outputs carry a 1e-5 tolerance.
                 const float iw = __builtin_amdgcn_rcpf(a[0] + a[1] + a[2]);
                 float b0 = __saturatef(a[0] * iw), b1 = __saturatef(a[1] * iw);
-                const float z = P[0].z * a[0] + P[1].z * a[1] + P[2].z * a[2];
-                const float w = P[0].w * a[0] + P[1].w * a[1] + P[2].w * a[2];
+                const float z = __fmaf_rn(P[2].z, a[2], __fmaf_rn(P[1].z, a[1], P[0].z * a[0]));
+                const float w = __fmaf_rn(P[2].w, a[2], __fmaf_rn(P[1].w, a[1], P[0].w * a[0]));
                 const float zw = fmaxf(fminf(z * __builtin_amdgcn_rcpf(w), 1.f), -1.f);
                 const float bs = __builtin_amdgcn_rcpf(fmaxf(b0 + b1, 1.f));     // renormalise after the clamp
                 b0 *= bs; b1 *= bs;
@@ -1144,8 +1397,8 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 
                 const float sx = p.xs * iw, sy = p.ys * iw;
                 const float DtX = DX[0] + DX[1] + DX[2], DtY = DY[0] + DY[1] + DY[2];
-                odb = make_float4(sx * (b0 * DtX - DX[0]), sy * (b0 * DtY - DY[0]),
-                                  sx * (b1 * DtX - DX[1]), sy * (b1 * DtY - DY[1]));
+                odb = make_float4(sx * __fmaf_rn(b0, DtX, -DX[0]), sy * __fmaf_rn(b0, DtY, -DY[0]),
+                                  sx * __fmaf_rn(b1, DtX, -DX[1]), sy * __fmaf_rn(b1, DtY, -DY[1]));
             }
         }
         if (write) {
@@ -1337,7 +1590,15 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 // Host side
 // ---------------------------------------------------------------------------------
 
-struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, poolPeak, order, splitInfo, helpers, splitDone, splitKeys, total; int slots, poolBase, maxBins, poolSlots; };
+struct ScratchLayout { size_t rec, bbox, pool, binCount, binHi, binLoInv, ctlEnd, poolFinal, poolPeak, order, splitInfo, helpers, splitDone, splitKeys, binCursor, anyList, binList, total; int slots, poolBase, maxBins, poolSlots; long long listCap; };
+
+// Per-bin triangle lists are made for meshes of kListMinTris triangles or more (NVDR_DEBUG bit 268435456: for every mesh,
+// bit 536870912: for none -- development switches for A/B measurements).
+static bool lists_enabled(int max_tri)
+{
+    if (debug_flags() & 536870912) return false;
+    return max_tri >= kListMinTris || (debug_flags() & 268435456) != 0;
+}
 
 // pool_per_image: slots per image for the clipper's extra sub-triangles; < 0 or >= 6 * max_tri = the worst case.
 static ScratchLayout scratch_layout(int N, int max_tri, int H, int W, long long pool_per_image = -1)
@@ -1367,11 +1628,25 @@ static ScratchLayout scratch_layout(int N, int max_tri, int H, int W, long long 
     L.order = align_up(L.poolPeak + 4, 256);
     // bins shared by several workgroups (k_order / k_fine): per work item a split descriptor, per XCD chunk the helper
     // items, per split an arrival counter and one key array per part (64 tiles x 64 pixels x 8 B)
-    L.splitInfo = align_up(L.order + (size_t)N * L.maxBins * 16, 256);
-    L.helpers = align_up(L.splitInfo + (size_t)N * L.maxBins * 4, 256);
-    L.splitDone = align_up(L.helpers + (size_t)8 * kHelpersPerChunk * 16, 256);
-    L.splitKeys = align_up(L.splitDone + (size_t)8 * kSplitsPerChunk * 4, 256);
-    L.total = align_up(L.splitKeys + (size_t)8 * kSplitsPerChunk * kSplitMaxParts * 4096 * 8, 256);
+    L.splitInfo = align_up(L.order + ((size_t)N * L.maxBins + 8) * 16, 256);          // (+ 8: a chunk's slots are the bins / 8 rounded up)
+    L.helpers = align_up(L.splitInfo + ((size_t)N * L.maxBins + 8) * 4, 256);
+    const int helpersPerChunk = lists_enabled(max_tri) ? kListHelpersPerChunk : kHelpersPerChunk;
+    L.splitDone = align_up(L.helpers + (size_t)8 * helpersPerChunk * 16, 256);
+    L.splitKeys = align_up(L.splitDone + (size_t)8 * kSplitsPerChunk * 4 * 3, 256);                 // arrival counters, then the splits' key-array numbers, then their bins
+    // key arrays of 64 x 64 keys: one per PART in small launches (the exchange of k_fine<SPLIT>), one per shared bin in launches
+    // over large meshes (k_fine<LIST>: kept at all ones between calls)
+    L.total = align_up(L.splitKeys + (size_t)8 * (lists_enabled(max_tri) ? kSplitsPerChunk : helpersPerChunk + kSplitsPerChunk) * 4096 * 8, 256);
+    // per-bin triangle lists (k_binscan / k_binfill), large meshes only: a cursor per bin, a flag per image, and room for two
+    // list entries per triangle (one per clipper slot, up to a triangle's worth of those) -- triangles are small next to a 64x64-pixel bin when there are this many of them; lists that do
+    // not fit are not made (their bins scan their slot range as before)
+    L.binCursor = L.anyList = L.binList = L.total; L.listCap = 0;
+    if (lists_enabled(max_tri)) {
+        L.binCursor = L.total;
+        L.anyList = align_up(L.binCursor + (size_t)N * L.maxBins * 4, 256);
+        L.binList = align_up(L.anyList + (size_t)N * 4, 256);
+        L.listCap = (long long)N * (2ll * L.poolBase + (L.poolSlots < L.poolBase ? L.poolSlots : L.poolBase));
+        L.total = align_up(L.binList + (size_t)L.listCap * 4, 256);
+    }
     return L;
 }
 
@@ -1477,8 +1752,11 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         const size_t histBytes = (size_t)3 * binsX * binsY * sizeof(int);
         // Every call leaves the control block zeroed (k_order); it is cleared here only when the caller
         // cannot vouch for that (first use of the buffer, another layout, a failed call).
-        if (!scratch_clean && tx == 0 && ty == 0)                  // later viewport tiles inherit the clean block from the tile before
+        if (!scratch_clean && tx == 0 && ty == 0) {                // later viewport tiles inherit the clean block from the tile before
             NVDR_HIP_CHECK(hipMemsetAsync(pool, 0, L.ctlEnd - L.pool, stream));
+            if (L.listCap > 0)                                     // the shared bins' key arrays of LIST launches rest at all ones
+                NVDR_HIP_CHECK(hipMemsetAsync(sb + L.splitKeys, 0xFF, (size_t)8 * kSplitsPerChunk * 4096 * 8, stream));
+        }
         {
             ProfileScope ps("raster_setup", stream);
             hipLaunchKernelGGL(k_setup, dim3((unsigned)((((long long)bpi * N + 7) / 8) * 8)), dim3(256), histBytes, stream, sp, bpi);
@@ -1489,15 +1767,39 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         // 512^2: k_fine 91 -> 57 us); with more, the helpers' extra list building costs more than the shorter tail
         // gains (batch 64: 126 -> 130 us).
         const bool dbgMode = debug_buffer() != nullptr || (debug_flags() & (4 | 8 | 16 | 128 | 256 | 512 | 2048 | 4096 | 8192)) != 0;
-        const bool split = !dbgMode && totalBins <= 2 * resident_fine_workgroups() && !(debug_flags() & 1048576);
-        const int splitTris = split ? kSplitTris : 0x7FFFFFFF, splitPart = kSplitPart;
+        const bool lists = L.listCap > 0 && !dbgMode;
+        // (launches over large meshes always share: one bin may hold more triangles than all the others together)
+        const bool split = !dbgMode && (lists || totalBins <= 2 * resident_fine_workgroups()) && !(debug_flags() & 1048576);
+        const int splitTris = !split ? 0x7FFFFFFF : lists ? tune_int("NVDR_TUNE_LIST_SPLIT_TRIS", kListSplitTris) : kSplitTris;
+        const int splitPart = lists ? tune_int("NVDR_TUNE_LIST_SPLIT_PART", kListSplitPart) : kSplitPart;
+        const int helpersPerChunk = L.listCap > 0 ? kListHelpersPerChunk : kHelpersPerChunk;     // (as the layout was sized)
+        int* binCursor = lists ? (int*)(sb + L.binCursor) : nullptr;
+        if (lists) {
+            ProfileScope ps("raster_binscan", stream);
+            const bool all = (debug_flags() & 268435456) != 0;                    // development: a list for every bin with triangles
+            hipLaunchKernelGGL(k_binscan, dim3(1), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, binCursor, (int*)(sb + L.anyList),
+                               totalBins, binsX * binsY, N, L.slots - L.poolBase, L.listCap, all ? 0 : kListScanFactor, all ? -1 : kListScanBias);
+            NVDR_LAUNCH_CHECK();
+        }
         {
             ProfileScope ps("raster_order", stream);
             hipLaunchKernelGGL(k_order, dim3(8), dim3(1024), 0, stream, binCount, binHi, binLoInv, pool, poolFinal, poolPeak, N, order, totalBins,
                                (int*)(sb + L.splitInfo), (int4*)(sb + L.helpers), (int*)(sb + L.splitDone), splitTris, splitPart,
-                               (int*)(sb + L.poolPeak + 16), binsX, binsY);
+                               (int*)(sb + L.poolPeak + 16), binsX, binsY, (const int*)binCursor,
+                               lists ? min(kListSplitMaxParts, tune_int("NVDR_TUNE_LIST_MAX_PARTS", kListSplitMaxParts)) : kSplitMaxParts, helpersPerChunk, (int*)(sb + L.splitDone) + 8 * kSplitsPerChunk,
+                               (split && N < 8 && !(debug_flags() & 1073741824)) ? 1 : 0, (int*)(sb + L.splitDone) + 16 * kSplitsPerChunk);
         }
         NVDR_LAUNCH_CHECK();
+        if (lists) {
+            ListParams lp;
+            lp.bbox = bbox; lp.ranges = ranges; lp.poolFinal = poolFinal; lp.binCursor = binCursor; lp.anyList = (int*)(sb + L.anyList);
+            lp.binList = (uint32_t*)(sb + L.binList); lp.instance = sp.instance; lp.N = N; lp.T = T; lp.poolBase = L.poolBase; lp.slots = L.slots;
+            lp.binsX = binsX; lp.binsY = binsY; lp.cap = L.listCap;
+            const int fpi = (L.slots + kFillSlots - 1) / kFillSlots;
+            ProfileScope ps("raster_binfill", stream);
+            hipLaunchKernelGGL(k_binfill, dim3((unsigned)fpi * N), dim3(kFillThreads), 0, stream, lp, fpi);
+            NVDR_LAUNCH_CHECK();
+        }
 
         FineParams fp;
         fp.rec = rec; fp.bbox = bbox; fp.poolFinal = poolFinal; fp.ranges = ranges; fp.pos = pos; fp.tri = tri;
@@ -1507,7 +1809,10 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.order = order;
         fp.splitInfo = (const int*)(sb + L.splitInfo); fp.helpers = (const int4*)(sb + L.helpers);
         fp.splitKeys = (unsigned long long*)(sb + L.splitKeys); fp.splitDone = (int*)(sb + L.splitDone);
+        fp.splitKeyBase = (const int*)(sb + L.splitDone) + 8 * kSplitsPerChunk;
+        fp.splitBin = (const int*)(sb + L.splitDone) + 16 * kSplitsPerChunk;
         fp.chunkNz = (const int*)(sb + L.poolPeak + 16);                                        // 8 ints behind the pool-demand counter
+        fp.binList = lists ? (const uint32_t*)(sb + L.binList) : nullptr;
         fp.tileFlags = (debug_flags() & 67108864) ? nullptr : tile_flags; fp.tfW = (W + 7) >> 3; fp.tfH = (H + 7) >> 3;   // (timing switch; use with 33554432)
         {
             const TileFlags tfv = tile_flags_view(fp.tileFlags, N, H, W);
@@ -1518,12 +1823,17 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         fp.ys = 2.f / (float)H; fp.yo = 1.f / (float)H - 1.f;
         fp.dbg = debug_flags();
         fp.dbgbuf = debug_buffer();
-        const int grid = ((totalBins + 7) / 8) * 8 + (split ? 8 * kHelpersPerChunk : 0);          // + the helper slots of every XCD
+        const int grid = ((totalBins + 7) / 8) * 8 + (split ? 8 * (lists ? kListHelpersPerChunk : kHelpersPerChunk) : 0);   // + the helper slots of every XCD
         {
             ProfileScope ps("raster_fine", stream);
 #define NVDR_FINE(PEEL, WD)                                                                                                    \
     do {                                                                                                                       \
         if (dbgMode)    hipLaunchKernelGGL((k_fine<PEEL, WD, true, false>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
+        else if (lists && split) {                                                                                             \
+            hipLaunchKernelGGL((k_fine<PEEL, WD, false, true, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);        \
+            hipLaunchKernelGGL((k_fine<PEEL, WD, false, true, true, true>), dim3(8 * kSplitsPerChunk), dim3(kFineThreads), 0, stream, fp);   \
+        }                                                                                                                      \
+        else if (lists)          hipLaunchKernelGGL((k_fine<PEEL, WD, false, false, true>), dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
         else if (split) hipLaunchKernelGGL((k_fine<PEEL, WD, false, true>),  dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
         else            hipLaunchKernelGGL((k_fine<PEEL, WD, false, false>), dim3(grid), dim3(kFineThreads), 0, stream, fp);  \
     } while (0)

@@ -77,6 +77,42 @@ def m10k_batch(N, seed=20240, nx=100, ny=50, attrs=4, pose_seed=None):
     return dict(pos=pos, tri=tri, attr=attr, uv=uv[None])
 
 
+def small_rotation(rng, max_deg):
+    """Rotation by at most ``max_deg`` degrees about a random axis (Rodrigues), as a 4x4 matrix."""
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    a = np.deg2rad(rng.uniform(-max_deg, max_deg))
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    out = np.eye(4)
+    out[:3, :3] = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+    return out
+
+
+def dense_batch(N, seed=20240, nx=100, ny=50, attrs=4, distance=1.45, max_deg=12.0):
+    """The benchmark's mesh with the camera pulled in until it fills the image (coverage >= 0.9, overdraw ~1):
+    the regime in which no consumer of ``rast`` can skip anything.  Same dict as ``m10k_batch``."""
+    rng = np.random.default_rng(seed)
+    verts, tri, uv = lattice_mesh(rng, nx, ny)
+    attr = rng.uniform(0.0, 1.0, size=(1, verts.shape[0], attrs)).astype(np.float32)
+    vh = np.concatenate([verts, np.ones((verts.shape[0], 1), np.float32)], 1).astype(np.float64)
+    proj = perspective(x=0.4, n=1.0, f=50.0).astype(np.float64) @ translation(0, 0, -distance).astype(np.float64)
+    pos = np.empty((N, verts.shape[0], 4), np.float32)
+    for n in range(N):
+        pose = small_rotation(np.random.default_rng(seed + 7000 + n), max_deg)
+        pos[n] = (vh @ (proj @ pose).T).astype(np.float32)
+    return dict(pos=pos, tri=tri, attr=attr, uv=uv[None])
+
+
+def big_mesh_batch(N, nx=1000, ny=500, seed=20240, attrs=4, shuffle=False):
+    """T = 2*nx*ny triangles (default one million) of the same kind of lattice, random poses as in ``m10k_batch``;
+    ``shuffle`` permutes the rows of ``tri`` -- the same surface, but its index order no longer says anything about where a
+    triangle lies on the screen (a triangle soup as far as the rasterizer's binning is concerned)."""
+    b = m10k_batch(N, seed=seed, nx=nx, ny=ny, attrs=attrs)
+    if shuffle:
+        b["tri"] = np.ascontiguousarray(b["tri"][np.random.default_rng(seed + 1).permutation(b["tri"].shape[0])])
+    return b
+
+
 def stress_triangles(N, T=10000, res=512, seed=20240):
     """S10k: independent triangles, centres U(-1,1)^2, edge length log-uniform [2,64] px,
     z U(-0.9,0.9), w = 1.  Returns dict(pos [N,3T,4], tri [T,3])."""

@@ -302,7 +302,7 @@ def test_scratch_sizes_of_the_two_policies():
     st = RasterizeCRStateWrapper(0)
     pool = st.pool_hint(N, T)
     small = lib.nvdr_rasterize_scratch_bytes_pool(N, T, 512, 512, pool)
-    assert pool == T // 4 and 5.0e9 < small < 5.8e9
+    assert pool == T // 4 and 5.0e9 < small < 6.1e9                        # (0.58 GB of it: the per-bin triangle lists of large meshes)
     assert lib.nvdr_rasterize_pool_peak_offset(N, T, 512, 512, pool) + 4 <= small
     assert st.pool_hint(2, 100) == 600                                   # small meshes: the complete worst case
     assert st.grow_pool(N, T, 400000) == 501024 and st.pool_hint(N, T) == 501024

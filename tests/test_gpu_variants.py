@@ -19,3 +19,17 @@ def test_rasterizer_tests_with_bin_sharing_disabled():
                        capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_rasterizer_tests_with_a_triangle_list_for_every_bin():
+    """Large meshes get per-bin triangle lists (k_binscan / k_binfill / k_fine<..., LIST>); the development switch makes
+    every mesh count as large and every bin with triangles take its list, so the rasterizer's own scenes -- peeling, range
+    mode, clipped triangles in the pool, viewport tiling, shared bins, the fuzz seeds -- run through that path as well."""
+    env = dict(os.environ, NVDR_DEBUG="268435456")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_raster_interp.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_edge_cases.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_bin_lists.py"),
+                        "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

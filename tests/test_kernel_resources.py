@@ -46,10 +46,14 @@ def _metadata(tmp_path, src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_rasterizer_kernels_stay_within_their_budgets(tmp_path):
     k = _metadata(tmp_path, "raster.hip")
-    fine = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb0EEEvNS_10FineParamsE"]            # production: no peel, no depth surface, no debug, no sharing
+    fine = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10FineParamsE"]       # production: no peel, no depth surface, no debug, no sharing, no lists
     assert fine == (0, fine[1]) and fine[1] <= 64, fine                         # 8 waves/SIMD, 4 workgroups/CU; not one spilled register
-    shared = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb1EEEvNS_10FineParamsE"]
+    shared = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb0ELb0EEEvNS_10FineParamsE"]
     assert shared[1] <= 64 and shared[0] <= 16, shared
+    for name in ("_ZN4nvdr6k_fineILb0ELb0ELb0ELb0ELb1ELb0EEEvNS_10FineParamsE", "_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb1ELb0EEEvNS_10FineParamsE",
+                 "_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb1ELb1EEEvNS_10FineParamsE"):
+        lists = k[name]                                                         # large meshes: bins with triangle lists
+        assert lists[1] <= 64 and lists[0] <= 32, (name, lists)
     grad = k["_ZN4nvdr13k_raster_gradILb0EEEvNS_10GradParamsEii"]
     assert grad[0] == 0 and grad[1] <= 80, grad                                 # 6 waves/SIMD
     setup = k["_ZN4nvdr7k_setupENS_11SetupParamsEi"]
@@ -94,7 +98,7 @@ def test_shared_bin_handoff_waits_for_its_exchanges_before_the_barrier(tmp_path)
     values are consumed after it).  Every k_fine<..., SPLIT> instantiation must have `s_waitcnt vmcnt(0)` between its
     last global_atomic_swap and the barrier that follows, and the arrival counter must be a release/acquire pair."""
     text = _assembly(tmp_path, "raster.hip")
-    names = re.findall(r"^(_ZN4nvdr6k_fineILb[01]ELb[01]ELb0ELb1EEEvNS_10FineParamsE):", text, flags=re.M)
+    names = re.findall(r"^(_ZN4nvdr6k_fineILb[01]ELb[01]ELb0ELb1ELb0ELb0EEEvNS_10FineParamsE):", text, flags=re.M)
     assert len(names) == 4, names
     for name in names:
         body = _kernel_body(text, name)
