@@ -12,6 +12,11 @@ Workloads (BASELINE.json `configs`):
   c2  configs[1]: the same graph, 16 items @512^2 on one GPU                            weak scaling
   c3  configs[2]: + 2048^2 mipmapped texture() + antialias(), 32 items per GPU @1024^2  weak scaling
   c4  configs[3]: 256 items @512^2 in total, 256/N per GPU (32 per GPU at N = 8)        strong scaling
+and the regimes the benchmark scene does not show: the same graph as ch on
+  dense         the benchmark mesh with the camera pulled in: coverage 1.0, overdraw ~1, 64 items @512^2
+  s10k          SURVEY 8(d)'s stress variant: 10 000 independent triangles of 2..64 px per item, 64 items @512^2
+  t1m           a one-million-triangle lattice mesh in index order, 2 items @1024^2
+  t1m_shuffled  the same mesh with the rows of `tri` permuted (a triangle soup as far as binning is concerned)
 
 One step = one pass of the hot path over the rank's items, inputs resident in HBM:
     rast, rast_db = rasterize(ctx, pos, tri, (H, W));  out, _ = interpolate(attr, rast, tri)
@@ -25,13 +30,20 @@ Timing: after W warm-up steps, `--windows` (default 5) windows of EXACTLY K step
 barrier + synchronize on both sides and timed with the host clock (max over ranks) and with a hipEvent pair;
 `ms_per_step` is the MEDIAN window, `ms_per_step_min/max` the spread (median over event pairs).
 
-Rank 0 prints ONE JSON line.  Beside the headline number it carries
+Rank 0 prints ONE JSON line -- a COMPACT record, under 8 KB (the driver keeps 8 KB of stdout) -- and writes the complete
+record, everything described below with all its prose, to `bench_detail.json` next to this file (the line names it).  Short
+keys of the line: kernels {name: [avg ms per launch, alg frac, req frac]}; configs.<name> {ms, gpix, cov, k {kernel: ms},
+dom [longest kernel, alg frac, req frac], path [alg frac, req frac], par {...}}.  Beside the headline number it carries
   roofline      the LONGEST kernel of the step (hipEvents recorded by the library on the launch stream):
                 `frac` = ALGORITHMIC bytes / time / 8 TB/s (SURVEY 8(d)'s convention: compulsory tensor traffic, whether or
                 not a kernel can skip part of it); `traffic` = the PMC-measured HBM bytes of that kernel per launch, taken
                 from profiles/traffic.json (a builder-session rocprofv3 measurement, named in `traffic_source` -- NOT
                 measured in this run); `hbm_frac_counter` = traffic / time / peak = the physically moved bytes' rate;
-  path_hbm_frac the whole step's algorithmic bytes / step time against the same peak;
+                `frac_required` = REQUIRED bytes / time / peak: writes for every pixel, reads only for what the kernel cannot
+                avoid -- rast / rast_db / uv of tiles the rasterizer flagged non-empty, upstream gradients of covered pixels
+                (from this run's coverage and tile flags) -- i.e. the bytes that do move; no bandwidth in the line exceeds the peak;
+  path_hbm_frac the whole step's algorithmic bytes / step time against the same peak; path_hbm_frac_required the same with
+                required bytes; path_hbm_frac_counter with the PMC-counted bytes of profiles/traffic.json (where they exist);
   cpu_baseline  the CPU oracle (a port of the reference's algorithm -- the reference has no CPU path) on this box's
                 host cores, bounded sample; cpu_reference = the reference's own kernels under the CUDA-on-CPU shim
                 of oracle/refshim (one thread), when oracle/_ref is present;
@@ -71,7 +83,33 @@ WORKLOADS = {
                metric="Mpixels/s rasterize+interpolate+texture(2048^2 mip)+antialias fwd+bwd @1024^2 batch32 (BASELINE configs[2])"),
     "c4": dict(per_gpu=None, total=256, res=512, graph="ri", scaling="strong", attrs=4,
                metric="Mpixels/s rasterize+interpolate fwd+bwd @512^2 batch256 sharded over the GPUs (BASELINE configs[3])"),
+    "dense": dict(per_gpu=64, total=None, res=512, graph="ri", scaling="weak", attrs=4, scene="dense",
+                  metric="Mpixels/s rasterize+interpolate fwd+bwd @512^2 batch64, camera pulled in (coverage 1.0)"),
+    "s10k": dict(per_gpu=64, total=None, res=512, graph="ri", scaling="weak", attrs=4, scene="s10k",
+                 metric="Mpixels/s rasterize+interpolate fwd+bwd @512^2 batch64, S10k stress triangles (SURVEY 8(d))"),
+    "t1m": dict(per_gpu=2, total=None, res=1024, graph="ri", scaling="weak", attrs=4, scene="t1m",
+                metric="Mpixels/s rasterize+interpolate fwd+bwd @1024^2 batch2, 1M-triangle mesh in index order"),
+    "t1m_shuffled": dict(per_gpu=2, total=None, res=1024, graph="ri", scaling="weak", attrs=4, scene="t1m_shuffled",
+                         metric="Mpixels/s rasterize+interpolate fwd+bwd @1024^2 batch2, 1M-triangle mesh, tri rows shuffled"),
 }
+PARITY_BAR = ("ids identical; forward floats 1e-5 abs; gradients 1e-5*max(1,|g|inf) -- every gradient is a SUM of per-pixel terms "
+              "(attr: all items into one tensor), so the bar is relative to its magnitude (tests/conftest.py)")
+
+
+def build_scene(name, N, A, dry=False, rank=0):
+    """The workload's geometry (numpy): pos [N,V,4], tri [T,3], attr [1,V,A], uv [1,V,2] where the scene has one."""
+    from nvdiffrast_amd.utils import m10k_batch, dense_batch, big_mesh_batch, stress_triangles
+    if dry:
+        return m10k_batch(N, seed=20240, attrs=A, nx=8, ny=4, pose_seed=20240 + 1000 * rank)
+    if name == "dense":
+        return dense_batch(N, attrs=A)
+    if name == "s10k":
+        b = stress_triangles(N, T=TRIANGLES, res=512)
+        b["attr"] = np.random.default_rng(3).uniform(size=(1, b["pos"].shape[1], A)).astype(np.float32)
+        return b
+    if name in ("t1m", "t1m_shuffled"):
+        return big_mesh_batch(N, attrs=A, shuffle=name.endswith("shuffled"))
+    return m10k_batch(N, seed=20240, attrs=A, pose_seed=20240 + 1000 * rank)
 
 
 KERNEL_PASSES = {"tex_grad": ("tex_grad_light", "tex_grad", "tex_grad_fold")}
@@ -103,6 +141,49 @@ def algorithmic_bytes(graph, P, A, T, N):
         "raster_grad_db": 48 * P,                               # R g_rast, g_rast_db, rast
     }
     return per_kernel, 384 * P
+
+
+def required_bytes(graph, P, A, T, N, cov, tile_cov):
+    """Bytes a kernel cannot avoid: writes for every pixel, reads only for non-empty 8x8 tiles (rast,
+    rast_db, uv, uv_da: `tile_cov` of the pixels) or covered pixels (upstream gradients the kernels fetch per pixel: `cov`)."""
+    if cov is None or tile_cov is None:
+        return {}, None
+    if graph == "ri":
+        k = {
+            "raster_setup": N * T * (12 + 48 + 68),
+            "raster_fine": 32 * P,
+            "interp_fwd": (16 * tile_cov + 4 * A) * P,
+            "interp_grad": (4 * A * cov + 16 * tile_cov + 16) * P,
+            "raster_grad": (16 * cov + 16 * tile_cov) * P,
+            "interp_raster_grad": (4 * A * cov + 16 * tile_cov + 16) * P,
+        }
+        step = k["raster_fine"] + k["interp_fwd"] + k["interp_raster_grad"]
+        return k, step
+    C = 3
+    k = {
+        "raster_setup": N * T * (12 + 48 + 68),
+        "raster_fine": 32 * P,
+        "interp_fwd_da": (32 * tile_cov + 12 * A) * P,
+        "tex_fwd": (12 * A * tile_cov + 4 * C) * P,
+        "aa_discontinuity": 16 * tile_cov * P,
+        "tex_grad": (4 * C + 12 * A * tile_cov + 12 * A) * P,
+        "interp_grad_da": (12 * A * cov + 64 * tile_cov + 32) * P,
+        "interp_raster_grad_da": (12 * A * cov + 64 * tile_cov + 32) * P,
+        "raster_grad_db": (32 * cov + 16 * tile_cov) * P,
+    }
+    step = (k["raster_fine"] + k["interp_fwd_da"] + k["tex_fwd"] + k["aa_discontinuity"] + 2 * 4 * C * P      # + antialias: out = color fwd, g_color = dy bwd
+            + k["tex_grad"] + k["interp_raster_grad_da"])
+    return k, step
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def free_port():
@@ -152,11 +233,12 @@ def plan_chunks(n_items, item_bytes, compute_ms, links):
                      "predicted_step_ms_by_chunks": table}
 
 
-def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduce_ms=0.03):
+def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduce_ms=0.03, gather_every=(4, 8)):
     """What the 1/2/4/8-GPU curve must look like from the link arithmetic alone: whole-job speed-up over
     one GPU with the image all-gather inside the step (every rank receives (N-1) x its own image bytes, one peer per
     link: floor = own bytes / 153 GB/s, whatever N) and without it (independent ranks + one small all-reduce)."""
-    out = {"with_image_gather": {}, "without_image_gather": {}, "assumes": "compute = %.4f ms per item (this run), "
+    out = {"with_image_gather": {}, "without_image_gather": {}, **{"gather_every_%d" % k: {} for k in gather_every},
+           "assumes": "compute = %.4f ms per item (this run), "
            "xGMI link %.0f GB/s at 100 %% efficiency, %.0f us for the shared-gradient all-reduce" % (ms_per_item, XGMI_LINK_GBS, allreduce_ms * 1e3)}
     items1 = per_gpu if scaling == "weak" else total
     t1 = items1 * ms_per_item
@@ -171,6 +253,11 @@ def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduc
         t_n = C + ar
         out["with_image_gather"][str(n)] = round((job_items / t_g) / (items1 / t1), 2)
         out["without_image_gather"][str(n)] = round((job_items / t_n) / (items1 / t1), 2)
+        for k in gather_every:
+            # the images of every k-th step only, their gather running behind the kernels of the k steps until the next one:
+            # k steps take max(k steps of kernels, one gather + the step it starts in)
+            t_k = max(k * t_n, (G + C / 2 + ar) if n > 1 else 0.0) / k
+            out["gather_every_%d" % k][str(n)] = round((job_items / t_k) / (items1 / t1), 2)
     return out
 
 
@@ -189,10 +276,9 @@ class DryKernels:
 class Job:
     """One workload on this rank: its tensors resident in device memory and the step the timed region repeats."""
 
-    def __init__(self, name, N, total_items, first, rank, world, dev, dry, res, distributed, chunks, gather):
+    def __init__(self, name, N, total_items, first, rank, world, dev, dry, res, distributed, chunks, gather, gather_every=1):
         import torch.distributed as dist
         from nvdiffrast_amd.parallel import broadcast_shared
-        from nvdiffrast_amd.utils import m10k_batch
         self.dist = dist
         self.name, self.wl = name, WORKLOADS[name]
         self.N, self.total_items, self.rank, self.world, self.dev, self.dry = N, total_items, rank, world, dev, dry
@@ -202,10 +288,12 @@ class Job:
         self.distributed, self.gather_on = distributed, gather
         # Per-item poses differ across ranks; geometry every item shares (tri, attr/uv, texture) comes from rank 0 over
         # RCCL, as it would in a data-parallel job.
-        if dry:
-            self.scene = m10k_batch(N, seed=20240, attrs=self.A, nx=8, ny=4, pose_seed=20240 + 1000 * rank)
-        else:
-            self.scene = m10k_batch(N, seed=20240, attrs=self.A, pose_seed=20240 + 1000 * rank)
+        self.scene_name = self.wl.get("scene", "m10k")
+        self.scene = build_scene(self.scene_name, N, self.A, dry, rank)
+        self.gather_every = max(1, int(gather_every))
+        self.step_index = 0
+        self.in_flight = []          # image gathers of earlier steps that may still be running (gather_every > 1)
+        self.literal = False         # step variant: SURVEY 8(d)'s literal `(out*G).sum().backward()`
         sc = self.scene
         self.pos = torch.from_numpy(sc["pos"]).to(dev).requires_grad_(True)
         self.tri = torch.from_numpy(sc["tri"]).to(dev)
@@ -238,9 +326,6 @@ class Job:
         self.last_rast = None
 
     def set_chunks(self, chunks):
-        self.set_chunks(chunks)
-
-    def set_chunks(self, chunks):
         """The rank's items are rendered in this many calls (chunks exist to overlap a chunk's image all-gather with the next
         chunk's kernels; without the gather one call is best: larger launches, and the rasterizer's work order needs 2048 bins)."""
         self.chunks = max(1, min(int(chunks), self.N))
@@ -268,21 +353,42 @@ class Job:
         self.shared.grad = None
         if self.full:
             self.tex.grad = None
+        # gather_every = k: the consumer of the complete batch of images (a logger, a discriminator on another rank ...) wants
+        # it every k-th step only; that step's all-gather then has k steps' worth of kernels to hide behind -- it is waited for
+        # when its receive buffers are needed again, k steps later (or at the end of the timed window)
+        gather_now = self.gather_on and self.step_index % self.gather_every == 0
+        self.step_index += 1
+        if gather_now:
+            for w, _keep in self.in_flight:
+                w.wait()
+            self.in_flight = []
         pending = []
         for c, (a, b) in enumerate(self.bounds):
             p = self.pos if self.chunks == 1 else self.pos[a:b]
             out, rast = self.render(p)
-            if self.gather_on:
+            if gather_now:
                 # the collective runs on RCCL's own stream, ordered after this chunk's kernels; the next chunk's
                 # kernels are issued right away and overlap it
-                work, self.gathered[c] = gather_items_async(out.detach(), out=self.gathered[c])
-                pending.append(work)
-            torch.autograd.backward(out, self.G if self.chunks == 1 else self.G[a:b])
+                src = out.detach()
+                work, self.gathered[c] = gather_items_async(src, out=self.gathered[c])
+                pending.append((work, src))
+            if self.literal:
+                (out * (self.G if self.chunks == 1 else self.G[a:b])).sum().backward()
+            else:
+                torch.autograd.backward(out, self.G if self.chunks == 1 else self.G[a:b])
             self.last_rast = rast
         if self.distributed:
             allreduce_shared_grads([self.shared] + ([self.tex] if self.full else []))
-        for w in pending:
+        if self.gather_every > 1:
+            self.in_flight += pending
+        else:
+            for w, _keep in pending:
+                w.wait()
+
+    def drain(self):
+        for w, _keep in self.in_flight:
             w.wait()
+        self.in_flight = []
 
     def fence(self):
         if not self.dry:
@@ -306,6 +412,7 @@ class Job:
             t0 = time.perf_counter()
             for _ in range(steps):
                 run()
+            self.drain()                                      # gathers still in flight belong to this window
             if not self.dry:
                 e1.record()
             self.fence()
@@ -326,6 +433,13 @@ class Job:
             return None
         return round(float((self.last_rast[..., 3] > 0).float().mean().item()), 4)
 
+    def tile_coverage(self):
+        """Fraction of the 8x8-pixel tiles of the last step with a covered pixel: what the consumers of rast cannot skip."""
+        if self.last_rast is None:
+            return None
+        c = (self.last_rast[..., 3] > 0).float()
+        return round(float(torch.nn.functional.max_pool2d(c[:, None], 8, ceil_mode=True).mean().item()), 4)
+
     def profile_kernels(self, prof_steps, ms_per_step):
         """Per-kernel hipEvent timing inside the library (one chunk per launch) -> (kernels, roofline, path_frac)."""
         lib, _capi = self.lib, self._capi
@@ -343,34 +457,42 @@ class Job:
         lib.nvdr_profile_reset()
         P_rank = self.N * self.RES * self.RES
         alg, path_bytes = algorithmic_bytes(self.wl["graph"], P_rank, self.A, int(self.tri.shape[0]), self.N)
+        req, req_path = required_bytes(self.wl["graph"], P_rank, self.A, int(self.tri.shape[0]), self.N, self.coverage(), self.tile_coverage())
+        frac = lambda b, ms: None if b is None else round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)    # noqa: E731
         kernels = {}
         for name, (total_ms, launches) in prof.items():
             avg_ms = total_ms / max(launches, 1)
-            b = alg.get(name)
+            b, rb = alg.get(name), req.get(name)
             kernels[name] = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches / prof_steps,
-                             "alg_bytes": b, "gbs": None if b is None else round(b / (avg_ms * 1e-3) / 1e9, 1)}
+                             "alg_bytes": b, "gbs": None if b is None else round(b / (avg_ms * 1e-3) / 1e9, 1),
+                             "required_bytes": None if rb is None else int(rb), "frac_alg": frac(b, avg_ms), "frac_required": frac(rb, avg_ms)}
         # One op spread over several launches is judged as ONE pass: its algorithmic bytes against the sum of its launches
         # (the texture gradient with caller scratch = k_tex_grad_light + k_tex_grad + k_tex_grad_fold).
         for pname, members in KERNEL_PASSES.items():
             have = [m for m in members if m in kernels]
             if len(have) > 1:
                 t = sum(kernels[m]["avg_ms"] * kernels[m]["launches_per_step"] for m in have)
-                b = alg.get(pname)
+                b, rb = alg.get(pname), req.get(pname)
                 for m in have:
-                    kernels[m]["alg_bytes"] = kernels[m]["gbs"] = None
+                    kernels[m]["alg_bytes"] = kernels[m]["gbs"] = kernels[m]["required_bytes"] = kernels[m]["frac_alg"] = kernels[m]["frac_required"] = None
                     kernels[m]["part_of"] = pname + "_pass"
                 kernels[pname + "_pass"] = {"avg_ms": round(t, 4), "launches_per_step": 1.0, "alg_bytes": b, "launches": have,
-                                            "gbs": None if b is None else round(b / (t * 1e-3) / 1e9, 1)}
+                                            "gbs": None if b is None else round(b / (t * 1e-3) / 1e9, 1),
+                                            "required_bytes": None if rb is None else int(rb), "frac_alg": frac(b, t), "frac_required": frac(rb, t)}
         # Dominant kernel (or pass) = the longest one (time per step), full stop.
         dominant = max((k for k in kernels if "part_of" not in kernels[k]),
                        key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches_per_step"])
         dk = kernels[dominant]
         traffic = source = None
+        path_counter = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")          # PMC-derived HBM bytes/launch, builder session
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(self.name, tj if self.name == "ch" else {})
+                ent = tj.get(self.name, {})
+                if self.N == self.wl["per_gpu"] and ent:
+                    counted = sum(v * kernels[k]["launches_per_step"] for k, v in ent.items() if k in kernels)
+                    path_counter = round(counted / (max(ms_per_step, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                 if self.N == self.wl["per_gpu"]:
                     members = kernels[dominant].get("launches")
                     traffic = ent.get(dominant) if not members else (sum(ent[m] for m in members) if all(m in ent for m in members) else None)
@@ -382,10 +504,13 @@ class Job:
                     "unit": "GB/s", "frac": None if dk["gbs"] is None else round(dk["gbs"] / HBM_PEAK_GBS, 4),
                     "frac_is": "algorithmic bytes (SURVEY 8(d)) / time / peak",
                     "traffic": traffic, "traffic_source": source if traffic else None,
+                    "required_bytes_per_launch": dk.get("required_bytes"), "frac_required": dk.get("frac_required"),
                     "traffic_ratio": None if not (traffic and dk["alg_bytes"]) else round(traffic / dk["alg_bytes"], 3),
                     "hbm_frac_counter": None if not traffic else round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel_avg_ms": dk["avg_ms"], "alg_bytes_per_launch": dk["alg_bytes"]}
-        path_frac = round((path_bytes / (max(ms_per_step, 1e-9) * 1e-3) / 1e9) / HBM_PEAK_GBS, 4)
+        path_frac = {"alg": round((path_bytes / (max(ms_per_step, 1e-9) * 1e-3) / 1e9) / HBM_PEAK_GBS, 4),
+                     "required": None if req_path is None else round((req_path / (max(ms_per_step, 1e-9) * 1e-3) / 1e9) / HBM_PEAK_GBS, 4),
+                     "counter": path_counter}
         return kernels, roofline, path_frac
 
     def checker(self):
@@ -400,7 +525,11 @@ class Job:
         err = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())   # noqa: E731
         mag = lambda a: float(np.abs(a).max())                                                            # noqa: E731
         if not self.full:
-            ns = min(2, self.N)
+            import oracle
+            big = self.scene_name.startswith("t1m")
+            if big:                                   # a million triangles: the reference under its CPU shim takes minutes; the C oracle, pinned to it by the tests, seconds
+                chk, chk_name = oracle, "oracle"
+            ns = 1 if big else min(2, self.N)
             ro, _ = chk.rasterize(sc["pos"][:ns], sc["tri"], (RES, RES))
             Gs = self.G[:ns].cpu().numpy()
             ga_o, gr_o, _ = chk.interpolate_grad(sc["attr"], ro, sc["tri"], Gs)
@@ -411,16 +540,30 @@ class Job:
             o_s, _ = dr.interpolate(attr_s, r_s, self.tri)
             torch.autograd.backward(o_s, self.G[:ns])
             r_h = r_s.detach().cpu().numpy()
-            return {"against": chk_name, "items": ns, "resolution": [RES, RES],
-                    "tri_id_mismatches": int((r_h[..., 3] != ro[..., 3]).sum()),
-                    "bary_max_abs_err": err(r_h[..., :3], ro[..., :3]),
-                    "g_attr_max_abs_err": err(attr_s.grad.cpu().numpy(), ga_o), "g_attr_max_abs": mag(ga_o),
-                    "g_pos_max_abs_err": err(pos_s.grad.cpu().numpy(), gp_o), "g_pos_max_abs": mag(gp_o)}
+            res = {"against": chk_name, "items": ns, "resolution": [RES, RES], "bar": PARITY_BAR,
+                   "tri_id_mismatches": int((r_h[..., 3] != ro[..., 3]).sum()),
+                   "bary_max_abs_err": err(r_h[..., :3], ro[..., :3]),
+                   "g_attr_max_abs_err": err(attr_s.grad.cpu().numpy(), ga_o), "g_attr_max_abs": mag(ga_o),
+                   "g_pos_max_abs_err": err(pos_s.grad.cpu().numpy(), gp_o), "g_pos_max_abs": mag(gp_o)}
+            if self.scene_name == "m10k" and self.N <= 64:
+                # ALL items of the batch against the C oracle (the reference sums attr's gradient over every item: the shared-
+                # attribute gradient of the full batch is the one number a two-item check cannot vouch for)
+                ra, _ = oracle.rasterize(sc["pos"], sc["tri"], (RES, RES))
+                ga_a, gr_a, _ = oracle.interpolate_grad(sc["attr"], ra, sc["tri"], self.G.cpu().numpy())
+                gp_a = oracle.rasterize_grad(sc["pos"], sc["tri"], ra, gr_a)
+                self.pos.grad = None; self.shared.grad = None
+                out, rast = self.render(self.pos)
+                torch.autograd.backward(out, self.G)
+                res["all_items"] = {"against": "oracle", "items": self.N,
+                                    "tri_id_mismatches": int((rast.detach()[..., 3].cpu().numpy() != ra[..., 3]).sum()),
+                                    "g_attr_max_abs_err": err(self.shared.grad.cpu().numpy(), ga_a), "g_attr_max_abs": mag(ga_a),
+                                    "g_pos_max_abs_err": err(self.pos.grad.cpu().numpy(), gp_a), "g_pos_max_abs": mag(gp_a)}
+            return res
         # four-op chain, one item at the config's own resolution and texture size: every op against the reference ON THE INPUTS
         # THE HIP PATH GAVE IT (oracle/chain.py explains why a chain through a texture is not judged end to end)
         from oracle.chain import four_op_chain
         res = four_op_chain(dr, self.ctx, self.topo, chk, sc["pos"][:1], sc["tri"], sc["uv"], self.tex_np, self.G[:1], (RES, RES), dev=dev)
-        res.update({"against": chk_name, "items": 1, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]),
+        res.update({"against": chk_name, "items": 1, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]), "bar": PARITY_BAR,
                     "compared": "each op on identical inputs (the HIP path's own intermediate tensors)"})
         return res
 
@@ -461,21 +604,21 @@ class Job:
         except Exception:  # noqa: BLE001
             affinity = None
         threads = oracle.num_threads()
-        cpu = {"value": round(nc * RES * RES / tmed / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-               "sample": f"{nc} of the {N} items of the same batch, fwd+bwd, median of {reps} (the reference has no CPU path; this is "
-                         f"the repo's C/OpenMP restatement, pinned to the reference by the tests). cores = the OpenMP team it ran "
-                         f"with, omp_get_max_threads() = {threads}: OpenMP sizes its default team from the CPUs this process may run "
-                         f"on (affinity mask: {affinity}), not from os.cpu_count() = {os.cpu_count()} logical CPUs of the host"}
+        cpu = {"value": round(nc * RES * RES / tmed / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+               "sample": f"{nc} of {N} items, fwd+bwd, median of {reps}",
+               "note": f"the reference has no CPU path; this is the repo's C/OpenMP restatement, pinned to the reference by the tests. "
+                       f"cores = the OpenMP team it ran with, omp_get_max_threads() = {threads}: OpenMP sizes its default team from the "
+                       f"CPUs this process may run on (affinity mask: {affinity}), not from os.cpu_count() = {os.cpu_count()} logical CPUs"}
         cpu_ref = None
         if oref.available():
             nr = min(4 if not self.full else 1, N)
             t1 = time.perf_counter()
             chain(oref, nr, self.G[:nr].cpu().numpy())
             tr = time.perf_counter() - t1
-            cpu_ref = {"value": round(nr * RES * RES / tr / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
-                       "sample": f"{nr} item(s) of the same batch, fwd+bwd, one run: the reference's own CUDA kernels and "
-                                 f"CudaRaster compiled for the host and executed by a fibre-based CUDA-on-CPU shim "
-                                 f"(oracle/refshim) -- an emulation on one thread, not a tuned CPU implementation"}
+            cpu_ref = {"value": round(nr * RES * RES / tr / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "reference", "cpu": cpu_model(),
+                       "sample": f"{nr} item(s), fwd+bwd, one run",
+                       "note": "the reference's own CUDA kernels and CudaRaster compiled for the host and executed by a fibre-based "
+                               "CUDA-on-CPU shim (oracle/refshim) -- an emulation on one thread, not a tuned CPU implementation"}
         return cpu, cpu_ref
 
 
@@ -521,8 +664,9 @@ def extra_config(name, dev, steps, warmup, windows, with_cpu, graph_too=False):
     P = N * wl["res"] * wl["res"]
     block = {"metric": wl["metric"], "value": round(P / (ms * 1e-3) / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(ms, 4),
              "steps": steps, "warmup": warmup, "timing": timing, "batch": N, "resolution": [wl["res"], wl["res"]],
-             "coverage": job.coverage(), "launch": "eager",
-             "roofline": roofline, "path_hbm_frac": path_frac, "kernels": kernels, "parity": job.parity()}
+             "triangles": int(job.tri.shape[0]), "coverage": job.coverage(), "tile_coverage": job.tile_coverage(), "launch": "eager",
+             "roofline": roofline, "path_hbm_frac": path_frac["alg"], "path_hbm_frac_required": path_frac["required"],
+             "path_hbm_frac_counter": path_frac["counter"], "kernels": kernels, "parity": job.parity()}
     if with_cpu:
         cpu, cpu_ref = job.cpu_baselines(4 if job.full else 16)
         block["cpu_baseline"], block["cpu_reference"] = cpu, cpu_ref
@@ -560,6 +704,9 @@ def main():
                     help="N > 1: the rank's items are rendered in this many chunks so that a chunk's image all-gather "
                          "overlaps the next chunk's kernels (default: from the link / host arithmetic, see plan_chunks; 1 at N = 1)")
     ap.add_argument("--no-gather-images", action="store_true", help="N > 1: keep the output images sharded (no all-gather in the step)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: all-gather the output images of every k-th step only, overlapped with the following steps (default 1 = "
+                         "every step, the number the metric is quoted on; k = 4 is the schedule the link arithmetic predicts to scale >= 6x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="default run: do not also measure BASELINE configs[1], [2], [4]")
     ap.add_argument("--cpu-items", type=int, default=64, help="items in the CPU-oracle sample")
@@ -569,6 +716,7 @@ def main():
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the N > 1 code path (process group, broadcast, chunked all-gather, all-reduce) even with one rank: "
                          "checks the RCCL calls on a 1-GPU box")
+    ap.add_argument("--detail", default=None, help="where the complete record goes (default: bench_detail.json next to this file)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo + stand-in kernels: exercises the multi-rank plumbing without GPUs")
     args = ap.parse_args()
 
@@ -632,7 +780,7 @@ def main():
     if not gather:
         chunks = args.chunks or 1
 
-    job = Job(args.workload, N, total_items, first, rank, world, dev, dry, RES, distributed, chunks, gather)
+    job = Job(args.workload, N, total_items, first, rank, world, dev, dry, RES, distributed, chunks, gather, args.gather_every)
 
     run = job.step
     if args.graph:
@@ -664,6 +812,7 @@ def main():
         ms_ng = ms_per_step
         if gather:
             planned = job.chunks
+            job.drain()
             job.gather_on = False
             job.set_chunks(1)                                     # (nothing to overlap: the rank's items in one call)
             host_ng, evt_ng = job.timed_windows(run, min(args.warmup, 2), args.steps, max(1, min(args.windows, 3)))
@@ -681,7 +830,7 @@ def main():
             "xgmi_floor_ms": round(img_bytes / (XGMI_LINK_GBS * 1e9) * 1e3, 4) if links else None,
             "ms_per_step_without_image_gather": round(ms_ng, 4),
             "value_without_image_gather": round(total_items * RES * RES / (ms_ng * 1e-3) / 1e6, 1),
-            "chunks": job.chunks, "chunk_plan": chunk_plan,
+            "chunks": job.chunks, "chunk_plan": chunk_plan, "gather_every": job.gather_every,
             # the curve the link arithmetic predicts, from THIS run's compute time per item (gather-free step / items)
             "predicted_scaling": predicted_scaling(ms_ng / max(N, 1), wl["scaling"], wl["per_gpu"] or N, wl["total"] or total_items, item_bytes),
         }
@@ -691,37 +840,51 @@ def main():
 
     result = None
     if rank == 0:
-        kernels = roofline = parity = cpu = cpu_ref = configs = None
-        path_frac = None
+        kernels = roofline = parity = cpu = cpu_ref = configs = literal = None
+        path_frac = {"alg": None, "required": None, "counter": None}
+        coverage = tile_cov = None
         if not dry:
+            coverage, tile_cov = job.coverage(), job.tile_coverage()
             kernels, roofline, path_frac = job.profile_kernels(max(3, min(args.steps, 10)), ms_per_step)
             if world == 1:
                 parity = job.parity()
                 if not args.no_cpu_baseline:
                     cpu, cpu_ref = job.cpu_baselines(args.cpu_items if not job.full else min(args.cpu_items, 4))
-        coverage = None if dry else job.coverage()
+            if world == 1 and not distributed and not args.graph:
+                # SURVEY 8(d)'s literal timed region, `(out * G).sum().backward()`: the same library work plus torch's
+                # element-wise multiply, reduction and their backward (three more passes over the output image)
+                job.literal = True
+                host_l, evt_l = job.timed_windows(job.step, 2, args.steps, max(1, min(args.windows, 3)))
+                job.literal = False
+                ms_l, _ = window_stats(host_l, evt_l, args.steps)
+                literal = {"ms_per_step": round(ms_l, 4), "value": round(P_total / (ms_l * 1e-3) / 1e6, 1),
+                           "what": "(out*G).sum().backward() instead of torch.autograd.backward(out, G)"}
         full = job.full
-        cfg = {"workload": "%s: random-pose 10k-triangle lattice mesh (T=%d, V=%d), %d items on this GPU of %d in total @%dx%d, %s, "
+        scene_txt = {"m10k": "random-pose 10k-triangle lattice mesh", "dense": "10k-triangle lattice mesh, camera pulled in",
+                     "s10k": "S10k stress triangles", "t1m": "1M-triangle lattice mesh, index order",
+                     "t1m_shuffled": "1M-triangle lattice mesh, tri rows shuffled"}[job.scene_name]
+        cfg = {"workload": "%s: %s (T=%d, V=%d), %d items on this GPU of %d in total @%dx%d, %s, "
                            "upstream grad fed to backward directly"
-                           % (args.workload.upper(), int(job.tri.shape[0]), int(job.pos.shape[1]), N, total_items, RES, RES,
+                           % (args.workload.upper(), scene_txt, int(job.tri.shape[0]), int(job.pos.shape[1]), N, total_items, RES, RES,
                               "rasterize+interpolate(uv,da)+texture(2048^2 trilinear)+antialias fwd+bwd" if full
                               else "A=%d attrs, rasterize+interpolate fwd+bwd" % job.A),
                "batch_per_gpu": N, "total_items": total_items, "resolution": [RES, RES], "triangles": int(job.tri.shape[0]),
-               "coverage": coverage,
+               "coverage": coverage, "tile_coverage": tile_cov,
                "parallelism": "dp%d (items sharded; per step: %sall-reduce of the shared-input gradients)"
-                              % (world, ("all-gather of the output images in %d chunks overlapped with rendering, " % job.chunks) if gather else ""),
-               "chunks": job.chunks, "gather_images": bool(gather),
+                              % (world, ("all-gather of the output images%s in %d chunks overlapped with rendering, "
+                                         % (" of every %d-th step" % job.gather_every if job.gather_every > 1 else "", job.chunks)) if gather else ""),
+               "chunks": job.chunks, "gather_images": bool(gather), "gather_every": job.gather_every,
                "launch": "hipGraph replay" if args.graph else "eager"}
-        # ---- the other BASELINE configs, same process, single GPU, default run only ------------------------------------
+        # ---- the other BASELINE configs and the regimes the benchmark scene hides: same process, single GPU, default run only ---
         if (not dry and world == 1 and not distributed and args.workload == "ch" and args.batch is None and args.res is None
                 and not args.graph and not args.no_extra_configs):
             del job
             torch.cuda.empty_cache()
             configs = {}
-            for name, st in (("c2", 20), ("c3", 6)):
+            for name, st in (("c2", 20), ("c3", 6), ("dense", 10), ("s10k", 6), ("t1m", 6), ("t1m_shuffled", 6)):
                 try:
-                    configs[name] = extra_config(name, dev, st, 3, 5, with_cpu=(name == "c3" and not args.no_cpu_baseline),
-                                                 graph_too=(name == "c2"))
+                    configs[name] = extra_config(name, dev, st, 3, 5 if name in ("c2", "c3") else 3,
+                                                 with_cpu=(name == "c3" and not args.no_cpu_baseline), graph_too=(name == "c2"))
                 except Exception as e:  # noqa: BLE001
                     configs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             try:
@@ -738,7 +901,8 @@ def main():
             "config": cfg,
             "timing": timing,
             "roofline": roofline,
-            "path_hbm_frac": path_frac,
+            "path_hbm_frac": path_frac["alg"], "path_hbm_frac_required": path_frac["required"], "path_hbm_frac_counter": path_frac["counter"],
+            "literal_step": literal,
             "kernels": kernels,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
@@ -757,8 +921,133 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        os.write(json_fd, (json.dumps(result) + "\n").encode())
+        detail = args.detail or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail, "w") as f:
+                json.dump(result, f, indent=1)
+        except OSError:
+            detail = None
+        line = compact_line(result, detail)
+        os.write(json_fd, (line + "\n").encode())
     os.close(json_fd)
+
+
+LINE_LIMIT = 7600          # bytes; the driver keeps the last 8 KB of stdout
+
+
+def _r(x, n=4):
+    return None if x is None else (round(x, n) if isinstance(x, float) else x)
+
+
+def _sig(x, n=3):
+    return None if x is None else float("%.*g" % (n, x))
+
+
+def compact_parity(p):
+    if not p:
+        return p
+    if "error" in p:
+        return p
+    out = {"vs": "ref" if "reference" in p.get("against", "") else "oracle", "items": p.get("items"), "ids": p.get("tri_id_mismatches"),
+           "bary": _sig(p.get("bary_max_abs_err"))}
+    for k in ("g_attr", "g_pos"):
+        if k + "_max_abs_err" in p:
+            out[k] = [_sig(p[k + "_max_abs_err"]), _sig(p[k + "_max_abs"])]
+    if "all_items" in p:
+        a = p["all_items"]
+        out["all"] = {"vs": "oracle", "items": a["items"], "ids": a["tri_id_mismatches"],
+                      "g_attr": [_sig(a["g_attr_max_abs_err"]), _sig(a["g_attr_max_abs"])], "g_pos": [_sig(a["g_pos_max_abs_err"]), _sig(a["g_pos_max_abs"])]}
+    chain = {}
+    for k in ("uv", "col", "aa"):                                  # four-op chain: forward errors, then [err, magnitude] of each gradient
+        if k + "_err" in p:
+            chain[k] = _sig(p[k + "_err"])
+    for k in ("rast_db", "uv_da", "g_col", "g_tex", "g_uv", "g_uv_da", "g_uvattr", "g_rast", "g_rast_db", "g_pos"):
+        if k + "_err" in p:
+            chain[k] = [_sig(p[k + "_err"]), _sig(p[k + "_max"])]
+    if chain:
+        out["ops"] = chain
+    return out
+
+
+def compact_kernels(kernels):
+    """{name: [avg ms per launch, algorithmic fraction of peak, required fraction of peak]} (passes included, members without fractions)."""
+    if not kernels:
+        return kernels
+    return {k: [_r(v["avg_ms"]), _r(v.get("frac_alg"), 3), _r(v.get("frac_required"), 3)] for k, v in kernels.items()}
+
+
+def compact_config(c):
+    if "error" in c:
+        return {"error": str(c["error"])[:160]}
+    if "iters_per_s" in c:                                          # the configs[4] stand-in
+        out = {"it_s": _r(c["iters_per_s"], 1), "loss": [_sig(c.get("loss_first")), _sig(c.get("loss_last"))]}
+        g = c.get("hipgraph_replay") or {}
+        out["graph_it_s"] = _r(g.get("iters_per_s"), 1) if "error" not in g else "error"
+        return out
+    rf = c["roofline"]
+    out = {"ms": c["ms_per_step"], "gpix": round(c["value"] / 1e3, 2), "cov": c.get("coverage"), "tcov": c.get("tile_coverage"),
+           "k": {k: _r(v["avg_ms"]) for k, v in c["kernels"].items() if "part_of" not in v or True},
+           "dom": [rf["kernel"], _r(rf["frac"], 3), _r(rf.get("frac_required"), 3)],
+           "path": [_r(c.get("path_hbm_frac"), 3), _r(c.get("path_hbm_frac_required"), 3), _r(c.get("path_hbm_frac_counter"), 3)],
+           "par": compact_parity(c.get("parity"))}
+    g = c.get("hipgraph_replay")
+    if g:
+        out["graph_ms"] = g.get("ms_per_step", "error")
+    if c.get("cpu_baseline"):
+        out["cpu"] = [c["cpu_baseline"]["value"], c["cpu_baseline"]["cores"]]
+    return out
+
+
+def compact_line(full, detail_path):
+    """The record the driver keeps: every contract key, numbers instead of prose, under LINE_LIMIT bytes."""
+    if full is None:
+        return json.dumps(None)
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "ms_per_step_min",
+                                "ms_per_step_max", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = full["config"]
+    t = full["timing"]
+    out["timing"] = {"windows": t["windows"], "ms_per_step_windows": t["ms_per_step_windows"], "hip_event_ms_per_step_median": t["hip_event_ms_per_step_median"]}
+    rf = full["roofline"]
+    if rf:
+        rf = dict(rf)
+        rf.pop("frac_is", None)
+        if rf.get("traffic_source"):
+            rf["traffic_source"] = "profiles/traffic.json (builder-session PMC passes, not this run)"
+    out["roofline"] = rf
+    for k in ("path_hbm_frac", "path_hbm_frac_required", "path_hbm_frac_counter"):
+        out[k] = full.get(k)
+    if full.get("literal_step"):
+        out["value_literal_step"] = full["literal_step"]["value"]
+        out["ms_literal_step"] = full["literal_step"]["ms_per_step"]
+    out["kernels"] = compact_kernels(full["kernels"])
+    for k in ("cpu_baseline", "cpu_reference"):
+        c = full.get(k)
+        out[k] = None if not c else {kk: c[kk] for kk in ("value", "unit", "cores", "kind", "cpu", "sample") if kk in c}
+    p = full.get("parity")
+    out["parity"] = None if not p else dict(compact_parity(p), bar=PARITY_BAR)
+    out["collective"] = full.get("collective")
+    cf = full.get("configs")
+    out["configs"] = None if cf is None else {k: compact_config(v) for k, v in cf.items()}
+    for k in ("dry_run", "backend", "gathered_rows_chunk0", "gathered_rows_total"):
+        if k in full:
+            out[k] = full[k]
+    out["detail"] = None if not detail_path else os.path.basename(detail_path)
+    line = json.dumps(out, separators=(",", ":"))
+    # never over the limit: shed the least important parts first (they remain in the detail file)
+    for shed in (("collective", "chunk_plan"), ("collective", "predicted_scaling", "assumes"), ("config", "workload"), ("timing",), ("parity", "bar")):
+        if len(line) <= LINE_LIMIT:
+            break
+        d = out
+        for k in shed[:-1]:
+            d = d.get(k) or {}
+        if isinstance(d, dict) and shed[-1] in d:
+            d[shed[-1]] = None
+            line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT and out.get("configs"):
+        for c in out["configs"].values():
+            c.pop("k", None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
 
 
 if __name__ == "__main__":

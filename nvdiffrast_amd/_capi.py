@@ -76,7 +76,8 @@ def ptr_array(tensors):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """The in-tree library; NVDR_LIB_PATH (development: A/B runs of two builds on the GPU box) names another one."""
+    return os.environ.get("NVDR_LIB_PATH") or _build.LIB_PATH
 
 
 def load():

@@ -133,6 +133,26 @@ __global__ __launch_bounds__(256) void k_aa_discontinuity(const AAParams p, int 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = bx * kAaBlockW + lane;
     const int row0 = by * kAaBlockH + wave * kAaRows;
+    // out = color for this block's pixels (torch_antialias.cpp:122 clones the whole image first): the launch visits every pixel
+    // exactly once, so the copy rides along -- its 8 C bytes per pixel stream while the id reads below wait for theirs -- instead
+    // of being a launch of its own in front (403 MB each way at config 3: 0.14 ms).  k_aa_analysis, the next launch, blends into it.
+    if (p.output) {
+        const int cols = min(kAaBlockW, p.width - bx * kAaBlockW);
+        const int rowFloats = cols * p.channels;
+#pragma unroll 1
+        for (int r = 0; r < kAaRows; r++) {
+            const int py = row0 + r;
+            if (py >= p.height) break;
+            const size_t base = ((size_t)bx * kAaBlockW + (size_t)p.width * (py + (size_t)p.height * pz)) * p.channels;
+            if (((((uintptr_t)(p.color + base)) | ((uintptr_t)(p.output + base))) & 15) == 0 && (rowFloats & 3) == 0) {   // 16-byte granules when the row allows it
+                const float4* s4 = (const float4*)(p.color + base);
+                float4* d4 = (float4*)(p.output + base);
+                for (int i = lane; i < (rowFloats >> 2); i += 64) d4[i] = s4[i];
+            } else {
+                for (int i = lane; i < rowFloats; i += 64) p.output[base + i] = p.color[base + i];
+            }
+        }
+    }
     uint32_t c1 = 0, c2 = 0;                                 // bit r: candidate (right / down) in row r of this lane
     int cnt = 0;
     if (px < p.width) {
@@ -496,8 +516,7 @@ extern "C" int nvdr_antialias_fwd(const float* color, const float* rast, const f
     NVDR_REQUIRE(((hash_bytes / 16) & (hash_bytes / 16 - 1)) == 0, "antialias_fwd: topology hash size is not a power of two");
     p.output = out; p.work = (int4*)work;
     const size_t P = (size_t)N * H * W;
-    // out = color (torch_antialias.cpp:122 clones), counters = 0.
-    NVDR_HIP_CHECK(hipMemcpyAsync(out, color, P * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    // counters = 0; out = color (torch_antialias.cpp:122 clones) is done by k_aa_discontinuity on the way.
     NVDR_HIP_CHECK(hipMemsetAsync(work, 0, 16, stream));
     {
         ProfileScope ps("aa_discontinuity", stream);
@@ -528,8 +547,12 @@ extern "C" int nvdr_antialias_grad(const float* color, const float* rast, const 
     if (work_bytes < nvdr_antialias_work_bytes(N, H, W)) { set_error("antialias_grad: work buffer too small"); return NVDR_ERR_SCRATCH; }
     p.dy = dy; p.work = (int4*)work; p.gradColor = g_color; p.gradPos = g_pos;
     const size_t P = (size_t)N * H * W;
-    // g_color = dy (torch_antialias.cpp:218 clones); g_pos is zero-filled by the caller.
-    NVDR_HIP_CHECK(hipMemcpyAsync(g_color, dy, P * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    // g_color = dy (torch_antialias.cpp:218 clones); g_pos is zero-filled by the caller.  (A copy in front of the sparse atomics of
+    // k_aa_grad: they may land on any pixel, so no single launch can order "copy this pixel" before "add to it" across workgroups.)
+    {
+        ProfileScope ps("aa_copy_bwd", stream);
+        NVDR_HIP_CHECK(hipMemcpyAsync(g_color, dy, P * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
     {
         ProfileScope ps("aa_grad", stream);
         hipLaunchKernelGGL(k_aa_grad, dim3(item_grid((long long)P * 2)), dim3(256), 0, stream, p);

@@ -111,6 +111,7 @@ __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b)
 struct SubTri {
     int px[3], py[3];
     uint32_t zx, zy, zb;
+    uint32_t zmin;             // lower bound of the triangle's depths (TriangleSetup.inl:158,176), for k_fine's per-tile depth cull
 };
 
 // U32 fixed-point depth plane depth(X, Y) = zb + zx * X + zy * Y (wrapping arithmetic), bit-compatible
@@ -223,13 +224,17 @@ __device__ bool snap_cull_setup(const Viewport& vp, const float (*v)[4], SubTri&
     int wv0y = py[0] + (vp.vph << (kSpLog2 - 1));
     setup_depth_plane(zv, wv0x - (1 << (kSpLog2 - 1)), wv0y - (1 << (kSpLog2 - 1)),
                       d1x, d1y, d2x, d2y, 1.0f / (float)area, st.zx, st.zy, st.zb);
+    {   // zmin = cvt.rni.sat.u32(min vertex depth - CR_LERP_ERROR(0)) & 0xfffff000 (TriangleSetup.inl:158,176; Constants.hpp:69)
+        const float zlo = fminf(fminf(zv[0], zv[1]), zv[2]) - 2200.0f;
+        st.zmin = (!(zlo > 0.0f) ? 0u : zlo >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)rintf(zlo)) & 0xFFFFF000u;
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) { st.px[k] = px[k]; st.py[k] = py[k]; }
     return true;
 }
 
 // Record layout (4 x uint4):
-//   q0 = {A0, B0, C0, A1}   q1 = {B1, C1, A2, B2}   q2 = {C2, zx, zy, zb}   q3 = {id, aabb, 0, 0}
+//   q0 = {A0, B0, C0, A1}   q1 = {B1, C1, A2, B2}   q2 = {C2, zx, zy, zb}   q3 = {id, aabb, zmin, 0}
 // with E_e(X,Y) = C_e + X*A_e + Y*B_e >= 0  <=>  pixel (X,Y) is inside edge e.
 __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri& s, int id, int* s_hist, uint4* stage, uint32_t* boxStage)
 {
@@ -272,7 +277,7 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     r[0] = make_uint4(A[0], B[0], C[0], A[1]);
     r[1] = make_uint4(B[1], C[1], A[2], B[2]);
     r[2] = make_uint4(C[2], s.zx, s.zy, s.zb);
-    r[3] = make_uint4((uint32_t)id, box, 0u, 0u);
+    r[3] = make_uint4((uint32_t)id, box, s.zmin, 0u);
     if (boxStage) *boxStage = box; else p.bbox[so] = box;         // direct slots: AABBs leave as whole rows too (k_setup)
 }
 
@@ -775,11 +780,20 @@ __global__ __launch_bounds__(1024) void k_order(int* __restrict__ binCount, int*
 // themselves are 64 bytes per bin in eight places (14 -> 7 us at the headline batch).
 // ---------------------------------------------------------------------------------
 constexpr int kFlagOrderThreads = 1024;
-__global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, const uint8_t* __restrict__ rowCov, int* __restrict__ order)
+constexpr int kFlagOrderSingle = 4096;                     // up to this many bins one workgroup does it all in one launch
+constexpr int kFlagOrderChunk = 2048;                      // beyond: bins per workgroup of the two-launch form (count, then place)
+constexpr int kFlagOrderMaxGroups = kOrderMaxBins / kFlagOrderChunk;      // 32 partial counts (raster scratch, behind chunkNz)
+// PHASE 0: the whole list by one workgroup (batches up to kFlagOrderSingle bins: one launch, 7 us at the headline batch).
+// PHASE 1 / 2: larger batches, where one workgroup's walk grows linearly with the batch (81 us at 16384 bins): every workgroup
+// counts the covered bins of its stretch into partial[] (1), then -- next launch -- places its stretch behind the stretches before
+// it (2).  The list is the same in both forms: covered bins in image-major order, then the others.
+template <int PHASE>
+__global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, const uint8_t* __restrict__ rowCov, int* __restrict__ order,
+                                                                  int* __restrict__ partial, int groups)
 {
     __shared__ int s_wave[kFlagOrderThreads / 64];
-    const int per = (t.nBins + kFlagOrderThreads - 1) / kFlagOrderThreads;         // <= 64 (kOrderMaxBins)
-    const int b0 = min((int)threadIdx.x * per, t.nBins), b1 = min(b0 + per, t.nBins);
+    const int per = (t.nBins + groups * kFlagOrderThreads - 1) / (groups * kFlagOrderThreads);         // <= 64 (kOrderMaxBins)
+    const int b0 = min(((int)blockIdx.x * kFlagOrderThreads + (int)threadIdx.x) * per, t.nBins), b1 = min(b0 + per, t.nBins);
     unsigned long long mask = 0ull;                         // bit i: bin b0 + i has a covered tile
     {
         // k_fine left one byte per bin and tile row (FineParams::rowCov): one 8-byte word per bin; rows beyond the image were
@@ -804,12 +818,19 @@ __global__ __launch_bounds__(kFlagOrderThreads) void k_flag_order(TileFlags t, c
     __syncthreads();
     int before = 0, nCov = 0;
     for (int w = 0; w < kFlagOrderThreads / 64; w++) { const int v = s_wave[w]; if (w < wave) before += v; nCov += v; }
-    int co = before + incl - c;                             // covered bins in front of this thread's run
+    if (PHASE == 1) { if (threadIdx.x == 0) partial[blockIdx.x] = nCov; return; }
+    int groupBase = 0;                                      // covered bins in the stretches before this workgroup's
+    if (PHASE == 2) {
+        int all = 0;
+        for (int g = 0; g < groups; g++) { const int v = partial[g]; if (g < (int)blockIdx.x) groupBase += v; all += v; }
+        nCov = all;
+    }
+    int co = groupBase + before + incl - c;                 // covered bins in front of this thread's run
     int eo = nCov + (b0 - co);                              // empty ones, behind all the covered
     for (int b = b0; b < b1; b++) {
         if ((mask >> (b - b0)) & 1ull) order[co++] = b; else order[eo++] = b;
     }
-    if (threadIdx.x == 0) order[t.nBins] = nCov;
+    if (threadIdx.x == 0 && blockIdx.x == 0) order[t.nBins] = nCov;
 }
 
 // ---------------------------------------------------------------------------------
@@ -840,13 +861,18 @@ struct FineParams {
 };
 
 
+#ifndef NVDR_EARLYZ
+#define NVDR_EARLYZ 0        // per-tile depth cull in k_fine: measured -7 % on S10k, +3 % on the dense scene, 8 B of scratch (r04j): off
+#endif
 constexpr int kQueueSize = 128;
 
 struct FineShared {
     uint32_t slot[kListCap];                               // bin triangle list: record slot of each entry
     uint32_t box[kListCap];                                // packed tile AABBs of the list entries
     unsigned long long key[kBinTiles][kBinTiles][64];      // per-pixel visibility keys of the bin [tileY][tileX][pixel]
-    uint32_t pfx[kListCap + 64];                           // exclusive prefix of the entries' (triangle, tile) pair counts
+    uint16_t pfx[kListCap + 64];                           // exclusive prefix of the entries' (triangle, tile) pair counts (<= 448 x 64)
+    uint16_t zmin16[kListCap];                             // upper half of the entries' depth lower bound (record q3.z), rounded down
+    uint32_t tileZ[kBinTiles * kBinTiles];                 // per tile: an upper bound (upper half + 1) of what every pixel's depth will end up at most
     uint16_t queue[kFineWaves][kQueueSize];                // per-wave ring of surviving pairs: entry | tileX << 9 | tileY << 12
     int count;
     int totalPairs;
@@ -905,6 +931,7 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     const uint32_t idk = ~q3.x;
     const int tile = tyl * kBinTiles + tx;
 
+
     // Fragments.  Triangles are small: a wave's 64 masks hold 4 fragments on average but 28 at the maximum
     // (measured on the headline batch), so letting every lane pop its own bits keeps 63 lanes waiting for the
     // fullest one.  Masks above kCoop fragments are therefore rasterised by the WHOLE wave, one lane per pixel
@@ -960,6 +987,25 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
             }
         } while (heavy);
     }
+}
+
+// One tile's depth bound for k_fine's per-tile depth cull, refreshed from the tile's keys: the largest depth any of its 64 pixels
+// holds NOW is an upper bound of what each will hold in the end (keys only go down), and an untouched pixel holds the far plane, so
+// the bound bites once the tile is covered -- by one triangle or by several together (the reference keeps the same maximum per
+// tile, FineRaster.inl:13-34).  Waves take turns: after every batch of 64 pairs a wave refreshes ONE tile, all tiles come round
+// every eight batches.  Racing plain stores are fine: every value ever stored is a valid bound.  No register of this survives.
+__device__ __forceinline__ void refresh_tile_bound(FineShared& sh, int tile)
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    uint32_t d = ((const uint32_t*)&sh.key[0][0][0])[(tile * 64 + l) * 2 + 1];      // the keys' upper halves are the depths
+    d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xb1, 0xf, 0xf, false));      // quad_perm [1,0,3,2]
+    d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x4e, 0xf, 0xf, false));      // quad_perm [2,3,0,1]
+    d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x114, 0xf, 0xf, false));     // row_shr:4
+    d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x118, 0xf, 0xf, false));     // row_shr:8
+    d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x142, 0xa, 0xf, false));     // row_bcast:15 -> rows 1, 3
+    d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x143, 0xc, 0xf, false));     // row_bcast:31 -> rows 2, 3
+    if (l == 63) sh.tileZ[tile] = (d >> 16) + 1u;                                             // (upper half, rounded up)
 }
 
 // DBG = development instrumentation (per-workgroup phase timestamps and experiment switches); the
@@ -1067,6 +1113,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; t++) sh.key[wave / kWavesPerRow][(wave % kWavesPerRow) * kTilesPerWave + t][lane] = kInit;
     if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; sh.ticket = 0; }
+    if (wave == 0) sh.tileZ[lane] = 0xFFFFFFFFu;
     __syncthreads();
 
     // DBG experiment: bins at or above a triangle threshold (NVDR_DEBUG bits 20..31, x16) skip their raster stage
@@ -1192,6 +1239,19 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 nx = max(x1 - x0 + 1, 0); ny = max(y1 - y0 + 1, 0);
                 if (nx == 0) ny = 0;
             };
+            // Per-tile depth cull (the reference's early-Z, FineRaster.inl:13-34,67-71,282): sh.tileZ bounds from above what every
+            // pixel of a tile can end up with (refresh_tile_bound); a (triangle, tile) pair whose triangle lies wholly behind that --
+            // its depth lower bound zmin, record q3.z -- cannot win a pixel and is dropped before coverage, fragments or atomics.
+            // Sixteen bits of depth decide (zmin rounded down, the bound up).  Here: the listed triangles' zmin, one gather per
+            // entry, while wave 0 scans.
+#if NVDR_EARLYZ
+            {
+                int tl;                                     // thread number taken afresh (wave is scalar): nothing of it stays live
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tl));
+                tl += wave * 64;
+                if (tl < cnt) sh.zmin16[tl] = (uint16_t)(grec[(size_t)sh.slot[tl] * 4 + 3].z >> 16);
+            }
+#endif
             if (wave == 0) {
                 // exclusive scan of the pair counts: lane l owns entries [l*7, l*7+7)
                 constexpr int kPer = (kListCap + 63) / 64;
@@ -1211,13 +1271,16 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
                 const int base = incl - sum;
 #pragma unroll
-                for (int i = 0; i < kPer; i++) { const int j = lane * kPer + i; if (j <= cnt) sh.pfx[j] = (uint32_t)(base + local[i]); }
+                for (int i = 0; i < kPer; i++) { const int j = lane * kPer + i; if (j <= cnt) sh.pfx[j] = (uint16_t)(base + local[i]); }
                 if (lane == 63) sh.totalPairs = incl;
             }
             __syncthreads();
             if (!(DBG && (p.dbg & 4))) {
                 const int total = sh.totalPairs;
                 int head = 0, qn = 0;
+#if NVDR_EARLYZ
+                int turn = wave;                            // the tile whose depth bound this wave refreshes next
+#endif
                 for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
                     const int q = q0 + lane;
                     const bool act = q < total;
@@ -1235,7 +1298,11 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     const int ky = (nx > 1) ? (int)(((float)k + 0.5f) / (float)nx) : k;   // exact for k < 64, nx <= 8
                     const int kx = k - ky * nx;
                     const int tx = x0 + kx - btx0, tyl = y0 + ky - bty0;
+#if NVDR_EARLYZ
+                    const bool keep = act && (uint32_t)sh.zmin16[j] <= sh.tileZ[tyl * kBinTiles + tx];
+#else
                     const bool keep = act;
+#endif
                     const uint64_t m = __ballot(keep);
                     if (keep) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
                         (uint16_t)((uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12));
@@ -1246,6 +1313,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                         __builtin_amdgcn_wave_barrier();
                         head = (head + 64) & (kQueueSize - 1);
                         qn -= 64;
+#if NVDR_EARLYZ
+                        refresh_tile_bound(sh, turn);
+                        turn = (turn + kFineWaves) & (kBinTiles * kBinTiles - 1);
+#endif
                     }
                 }
                 if (qn > 0) {
@@ -1848,7 +1919,16 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         const TileFlags tf = tile_flags_view(tile_flags, N, H, W);
         if (tf.order) {
             ProfileScope ps("raster_flag_order", stream);
-            hipLaunchKernelGGL(k_flag_order, dim3(1), dim3(kFlagOrderThreads), 0, stream, tf, tile_flags + tile_flags_rowcov_offset(tile_flags_order_offset(N, H, W), tf.nBins), (int*)tf.order);
+            const uint8_t* rowCov = tile_flags + tile_flags_rowcov_offset(tile_flags_order_offset(N, H, W), tf.nBins);
+            int* partial = (int*)(sb + L.poolPeak + 64);                                 // 32 ints behind the pool counter and chunkNz
+            const int single = tune_int("NVDR_TUNE_FLAG_ORDER_SINGLE", kFlagOrderSingle);
+            if (tf.nBins <= single) {
+                hipLaunchKernelGGL(k_flag_order<0>, dim3(1), dim3(kFlagOrderThreads), 0, stream, tf, rowCov, (int*)tf.order, partial, 1);
+            } else {
+                const int groups = min(kFlagOrderMaxGroups, (tf.nBins + kFlagOrderChunk - 1) / kFlagOrderChunk);
+                hipLaunchKernelGGL(k_flag_order<1>, dim3(groups), dim3(kFlagOrderThreads), 0, stream, tf, rowCov, (int*)tf.order, partial, groups);
+                hipLaunchKernelGGL(k_flag_order<2>, dim3(groups), dim3(kFlagOrderThreads), 0, stream, tf, rowCov, (int*)tf.order, partial, groups);
+            }
             NVDR_LAUNCH_CHECK();
         }
     }

@@ -11,6 +11,9 @@ unchanged on top of this module.
 There is no CPU path: non-GPU tensors are rejected with the reference's messages and a
 missing native library raises at first use.
 """
+import os
+import weakref
+
 import torch
 
 from .. import _capi
@@ -43,10 +46,21 @@ def set_fused_backward(mode):
     """Not in the reference.  "auto" (default) or "off"."""
     assert mode in ("auto", "off")
     _fused["mode"] = mode
+    if mode == "auto":
+        _fused_epoch[0] += 1
 
 
 def fused_backward_mode():
     return _fused["mode"]
+
+
+_fused_epoch = [0]
+
+
+def fused_backward_epoch():
+    """Contexts remember WHEN a prepared gradient was discarded on them; set_fused_backward("auto") starts a new epoch, which
+    re-arms them all (one debugging step with a mask built from rast need not cost the fused kernel for the rest of the run)."""
+    return _fused_epoch[0]
 
 
 def fused_backward_count(what=None):
@@ -165,7 +179,7 @@ class RasterizeCRStateWrapper:
         self.cuda_device_idx = int(cuda_device_idx)
         self.scratch = None
         self.clean_layout = None
-        self.fused_disabled = False   # ops.py: a prepared fused backward was discarded once on this context -> stop preparing
+        self.fused_disabled = -1      # ops.py: the fused-backward epoch in which a prepared gradient was discarded on this context (-> stop preparing)
         self.captured = False    # some call of this context was recorded into a hipGraph
         self.retired = []        # scratch buffers that recorded graphs still point to
         self.reported_bytes = 0
@@ -312,7 +326,103 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     _capi.check(rc, fn)
     state.mark_clean(layout)
     state.last_flags = flags
+    _attach_tiles(out, flags, "rast")
     return out, out_db
+
+
+# ---- tile occupancy records -----------------------------------------------------------------------------------------------
+# rasterize_fwd_cuda leaves with its `rast` a record of the tile flags the rasterizer wrote for it; interpolate_fwd* leave with
+# their outputs a record of the same flags as "tiles of zeros".  Every entry point that reads such a tensor looks the record up
+# ITSELF when the caller passes no `tile_flags` -- so a caller that binds this module exactly like the reference's ops.py binds
+# _nvdiffrast_c, with no extra arguments, gets the empty-tile skipping too.  A record is honoured only
+# while the tensor is what it was: same storage, same version counter, same shape.  Deviation from the reference that this
+# cannot see: writes that do not bump the version counter (`rast.data[...] = x`, an external kernel writing through data_ptr).
+# `set_tile_skipping(False)` switches the whole mechanism off; `set_tile_flag_verification(True)` (or NVDR_VERIFY_TILE_FLAGS=1)
+# re-derives the flags from the tensor actually passed on every use and raises when they disagree.
+_tiles = {"skip": True, "verify": os.environ.get("NVDR_VERIFY_TILE_FLAGS", "0") not in ("", "0"), "verified": 0}
+_tile_registry = {}          # data_ptr -> weakref of the tensor that carries the record (for tensors autograd hands back as copies)
+
+
+def set_tile_skipping(enable):
+    """Not in the reference.  True (default): kernels that read a rast / rast_db / uv / uv_da tensor skip the 8x8 tiles the
+    rasterizer found empty while the tensor is untouched (version counter).  False: every pixel is read, as in the reference."""
+    _tiles["skip"] = bool(enable)
+
+
+def set_tile_flag_verification(enable):
+    """Not in the reference.  Debug mode: before every use of tile flags, recompute them from the tensor that was passed (one
+    host synchronisation per use) and raise RuntimeError if a tile flagged empty is not.  Also: NVDR_VERIFY_TILE_FLAGS=1."""
+    _tiles["verify"] = bool(enable)
+
+
+def tile_flag_verifications():
+    return _tiles["verified"]
+
+
+class _TileRecord:
+    """kind "rast": flag 0 = no pixel of the tile shows a triangle; kind "zero": flag 0 = every element of the tile is zero."""
+    __slots__ = ("flags", "ptr", "version", "shape", "kind", "__weakref__")
+
+    def __init__(self, flags, t, kind):
+        self.flags, self.ptr, self.version, self.shape, self.kind = flags, t.data_ptr(), t._version, tuple(t.shape[:3]), kind
+
+    def still(self, t):
+        return t.data_ptr() == self.ptr and t._version == self.version and tuple(t.shape[:3]) == self.shape
+
+
+def _attach_tiles(t, flags, kind):
+    t._nvdr_tiles = _TileRecord(flags, t, kind)
+    ptr = t.data_ptr()
+
+    def _forget(_ref, ptr=ptr):
+        if _tile_registry.get(ptr) is _ref:
+            del _tile_registry[ptr]
+    _tile_registry[ptr] = weakref.ref(t, _forget)
+
+
+def _record_of(t, kind):
+    """The valid record of `t`, found on the tensor itself or -- for the detached copies autograd returns for a Function's saved
+    OUTPUTS -- on the tensor that carries it, if that one is still alive (its storage then cannot have been recycled)."""
+    rec = getattr(t, "_nvdr_tiles", None)
+    if rec is None:
+        ref = _tile_registry.get(t.data_ptr())
+        owner = ref() if ref is not None else None
+        if owner is not None and owner.data_ptr() == t.data_ptr():
+            rec = getattr(owner, "_nvdr_tiles", None)
+    if rec is None or rec.kind != kind or not rec.still(t):
+        return None
+    return rec
+
+
+def _verify_tiles(fn, t, flags, kind):
+    if torch.cuda.is_current_stream_capturing():
+        return
+    n, h, w = (int(x) for x in t.shape[:3])
+    grid = tile_flags_grid(flags, n, h, w)
+    live = (t[..., 3] > 0) if kind == "rast" else (t != 0).any(-1)
+    occ = torch.nn.functional.max_pool2d(live.float()[:, None], 8, ceil_mode=True)[:, 0] > 0
+    bad = int(((grid == 0) & occ).sum().item())
+    _tiles["verified"] += 1
+    if bad:
+        _fail(fn, "tile flags disagree with the tensor they are used with: %d tile(s) flagged empty are not (was the tensor "
+                  "written to without bumping its version counter?)" % bad)
+
+
+def _auto_flags(fn, tile_flags, kind, *tensors):
+    """What an entry point uses as tile flags: the caller's (a tensor), none (False, or skipping switched off), or -- None -- the
+    flags of the records of ALL `tensors` (they must agree)."""
+    if tile_flags is False or not _tiles["skip"]:
+        return None
+    if tile_flags is None:
+        for t in tensors:
+            rec = _record_of(t, kind)
+            if rec is None or (tile_flags is not None and rec.flags is not tile_flags):
+                return None
+            tile_flags = rec.flags
+    if tile_flags is not None and _tiles["verify"]:
+        for t in tensors:
+            _verify_tiles(fn, t, tile_flags, kind)
+    return tile_flags
 
 
 def tile_flags_bytes(n, h, w):
@@ -376,6 +486,7 @@ def rasterize_grad_db(pos, tri, out, dy, ddb, tile_flags=None):
     dy_ = dy.contiguous()
     ddb_ = ddb.contiguous() if enable_db else None
     V = pos.size(1) if instance_mode else pos.size(0)
+    tile_flags = _auto_flags(fn, tile_flags, "rast", out)
     with _on_device(dev):
         grad = torch.zeros_like(pos)
         rc = _capi.load().nvdr_rasterize_grad(pos.data_ptr(), tri.data_ptr(), out.data_ptr(), dy_.data_ptr(),
@@ -440,6 +551,7 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec,
     N, H, W = rast.size(0), rast.size(1), rast.size(2)
     D = (A if diff_attrs_all else len(diff_attrs_vec)) if enable_da else 0
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
+    tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
     with _on_device(dev):
         out = torch.empty((N, H, W, A), dtype=torch.float32, device=dev)
         out_da = torch.empty((N, H, W, 2 * D), dtype=torch.float32, device=dev)
@@ -451,6 +563,12 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec,
                                                out.data_ptr(), out_da.data_ptr() if enable_da else None,
                                                _flags_ok(fn, tile_flags, N, H, W, dev), _stream(dev))
     _capi.check(rc, fn)
+    if tile_flags is not None:
+        # zeros are written where no triangle is visible: the rasterizer's empty tiles are tiles of zeros in both outputs, and
+        # texture() need not read them there (while the tensors stay what they are now)
+        _attach_tiles(out, tile_flags, "zero")
+        if out_da.numel():
+            _attach_tiles(out_da, tile_flags, "zero")
     return out, out_da
 
 
@@ -504,6 +622,7 @@ def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_
     dy_ = dy.contiguous()
     dda_ = dda.contiguous() if enable_da else None
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
+    tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
     with _on_device(dev):
         g_attr = torch.zeros_like(attr)
         g_rast = torch.empty_like(rast)
@@ -575,6 +694,7 @@ def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_
     lst, nlst = _diff_list([] if (diff_attrs_all or not enable_da) else diff_attrs_vec)
     with _on_device(dev):
         # both zero-initialised gradients from ONE buffer: one fill launch instead of two (small batches are launch-bound)
+        tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
         na = (attr.numel() + 3) & ~3                       # keeps g_pos 16-byte aligned
         zeros = torch.zeros((na + pos.numel(),), dtype=torch.float32, device=dev)
         g_attr = zeros[:attr.numel()].view(attr.shape)
@@ -763,6 +883,8 @@ def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filt
     tn, th, tw, C = _tex_dims(tex, boundary_mode == _BOUNDARY_CUBE)
     n, H, W = uv.size(0), uv.size(1), uv.size(2)
     ptrs, L = _capi.ptr_array(levels)
+    tile_flags = None if boundary_mode == _BOUNDARY_CUBE else \
+        _auto_flags(fn, tile_flags, "zero", *([uv, uv_da] if (enable_mip and has_uv_da) else [uv]))
     with _on_device(dev):
         out = torch.empty((n, H, W, C), dtype=torch.float32, device=dev)
         rc = _capi.load().nvdr_texture_fwd(tex.data_ptr(), ptrs, L, uv.data_ptr(),
@@ -808,6 +930,8 @@ def texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, mip_level_bias, mip_wr
         # scratch for the two-level reduction of constant-uv regions (include/nvdr_hip.h); not worth a second launch for
         # images of a few blocks
         lib = _capi.load()
+        tile_flags = None if boundary_mode == _BOUNDARY_CUBE else \
+            _auto_flags(fn, tile_flags, "zero", *([uv, uv_da] if (enable_mip and has_uv_da) else [uv]))
         scratch = None
         if _TEX_GRAD_SCRATCH and filter_mode != _FILTER_NEAREST and boundary_mode != _BOUNDARY_CUBE and n * H * W >= 4096:
             scratch = torch.empty((lib.nvdr_texture_grad_scratch_bytes(n, H, W, C) // 4,), dtype=torch.int32, device=dev)
@@ -904,6 +1028,7 @@ def antialias_fwd(color, rast, pos, tri, topology_hash_wrap, tile_flags=None):
     N, H, W, C = color.shape
     V = pos.size(1 if instance_mode else 0)
     lib = _capi.load()
+    tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
     with _on_device(dev):
         out = torch.empty_like(color)                                                   # the library copies color into it
         work_buffer = torch.empty((N * W * H * 8 + 4,), dtype=torch.float32, device=dev)

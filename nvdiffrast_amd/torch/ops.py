@@ -139,7 +139,7 @@ class _RasterOrigin:
         untouched, the same triangle tensor (pose-style scripts interpolate with another index buffer), one vertex set,
         nobody else doing the same."""
         st = self.state
-        return (_plugin.fused_backward_mode() == "auto" and not st.fused_disabled and self.pending is None
+        return (_plugin.fused_backward_mode() == "auto" and st.fused_disabled != _plugin.fused_backward_epoch() and self.pending is None
                 and self.interpolations == 1 and rast.requires_grad and self.pos.requires_grad
                 and rast.data_ptr() == self.rast_ptr and rast._version == self.rast_version and tuple(rast.shape) == self.rast_shape
                 and (rast_db is None or (rast_db.data_ptr() == self.db_ptr and rast_db._version == self.db_version))
@@ -207,7 +207,10 @@ class _RasterizeOp:
             # rast's gradient has other contributors in this program: what was prepared is void, and preparing it again
             # on this context would be wasted work every step
             _plugin.fused_backward_count("discarded")
-            origin.state.fused_disabled = True
+            if origin.state.fused_disabled != _plugin.fused_backward_epoch():
+                _plugin._log_info("fused rasterize/interpolate backward switched off on this context: rast's gradient has other "
+                                  "contributors (set_fused_backward('auto') re-arms it)")
+            origin.state.fused_disabled = _plugin.fused_backward_epoch()
         if d_rast is None:
             if not grad_db:
                 return (None,) * 7
@@ -249,6 +252,9 @@ class _InterpolateOp:
         """Gradient without pixel differentials; with the position gradient prepared in the same pass when the rast
         came straight from rasterize() and this is its only interpolation (see _RasterOrigin)."""
         flags = None if origin is None else origin.flags_for(rast)
+        if origin is not None and origin.pending is not None:
+            origin.pending = None          # left over from a backward pass that never reached the rasterize node
+            #                                (autograd.grad(inputs=[attr]), an exception): void, and must not block or pin memory
         if origin is not None and origin.usable_by(attr, rast, tri):
             g_attr, g_rast, _, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, tile_flags=flags)
             origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos, None)
@@ -267,6 +273,8 @@ class _InterpolateOp:
         if with_da:
             attr, rast, tri, rast_db = saved
             flags = None if origin is None else origin.flags_for(rast)
+            if origin is not None and origin.pending is not None:
+                origin.pending = None      # (stale, as in _plain_grad)
             if origin is not None and origin.usable_by(attr, rast, tri, rast_db):
                 # config 3's pair: interpolate_grad_da + rasterize_grad_db in one pass (see _RasterOrigin)
                 g_attr, g_rast, g_rast_db, g_pos = _plugin.interpolate_rasterize_grad(

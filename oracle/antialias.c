@@ -139,6 +139,12 @@ static void analyze(const AACfg* p, int px, int py, int pz, int d, AAItem* it)
     int op0 = edge_find(p->map, vi2, vi1, vi0);
     int op1 = edge_find(p->map, vi0, vi2, vi1);
     int op2 = edge_find(p->map, vi1, vi0, vi2);
+    /* The table is built without knowing V (torch_antialias.cpp:40 sets numVertices = 0x7fffffff), so a triangle with an index
+     * >= V puts that index into it as an opposite vertex, and the reference then reads pos[] out of bounds here (:282-300):
+     * undefined.  Defined here as "no opposite vertex" (what nvdiffrast_amd does); oracle/pinned.py does not pin such tables. */
+    if (op0 >= p->V) op0 = -1;
+    if (op1 >= p->V) op1 = -1;
+    if (op2 >= p->V) op2 = -1;
     size_t vb = p->instance ? (size_t)pz * p->V : 0;
     const float* P0 = p->pos + (vb + vi0) * 4;
     const float* P1 = p->pos + (vb + vi1) * 4;

@@ -201,13 +201,22 @@ class PinnedOracle:
     # ------------------------------------------------------------------ antialias
     def antialias(self, color, rast, pos, tri):
         out = self._o.antialias(color, rast, pos, tri)
-        if self.enabled and self._small_enough(rast):
-            self._close("antialias", "out", out, _ref.antialias(color, rast, pos, tri), rtol=FWD_ATOL)
+        # (a table with indices >= V makes the reference read pos[] out of bounds -- see oracle/antialias.c analyze(): not pinned)
+        if self.enabled and self._small_enough(rast) and int(np.max(tri, initial=0)) < np.shape(pos)[-2]:
+            r = _ref.antialias(color, rast, pos, tri)
+            try:
+                self._close("antialias", "out", out, r, rtol=FWD_ATOL)
+            except PinMismatch:
+                d = os.environ.get("NVDR_PIN_DUMP")          # development: keep the case for a replay on the CPU
+                if d:
+                    np.savez(os.path.join(d, "antialias_case.npz"), color=color, rast=rast, pos=pos, tri=tri, oracle=out, ref=r,
+                             oracle2=self._o.antialias(color, rast, pos, tri), ref2=_ref.antialias(color, rast, pos, tri))
+                raise
         return out
 
     def antialias_grad(self, color, rast, pos, tri, dy):
         gc, gp = self._o.antialias_grad(color, rast, pos, tri, dy)
-        if self.enabled and self._small_enough(rast):
+        if self.enabled and self._small_enough(rast) and int(np.max(tri, initial=0)) < np.shape(pos)[-2]:
             rc, rp = _ref.antialias_grad(color, rast, pos, tri, dy)
             self._close("antialias_grad", "g_color", gc, rc, rtol=GRAD_RTOL)
             self._close("antialias_grad", "g_pos", gp, rp, rtol=GRAD_RTOL)

@@ -94,3 +94,17 @@ def test_eight_ranks_c4():
     assert j["gathered_rows_total"] == 256                                            # 8 ranks x 32 items arrived on rank 0
     assert j["timing"]["windows"] == 2 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
     assert j["collective"]["xgmi_links_per_gpu_used"] == 7
+
+
+def test_gather_every_kth_step_at_world_8():
+    """the one schedule with an image gather that the link arithmetic lets scale: the complete batch of
+    images every k-th step only, its all-gather running behind the following steps' kernels (double-buffered receive)."""
+    j = _run("--gpus", "8", "--workload", "c4", "--windows", "2", "--gather-every", "4", "--steps", "5")
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["config"]["gather_every"] == 4 and j["config"]["gather_images"] is True
+    assert j["gathered_rows_total"] == 256                                   # the gathered batch is complete when it is there
+    assert set(j["collective"]["predicted_scaling"]) >= {"with_image_gather", "without_image_gather", "gather_every_4", "gather_every_8"}
+    # (the dry run's items are 32x32 stand-ins; the arithmetic with this tree's measured 6.6 us per item at 512^2:)
+    sys.path.insert(0, ROOT)
+    import bench
+    pw = bench.predicted_scaling(0.0066, "weak", 64, None, 512 * 512 * 4 * 4)
+    assert pw["gather_every_4"]["8"] >= 6.0 and pw["gather_every_8"]["8"] >= 7.0 and pw["with_image_gather"]["8"] < 3.0

@@ -12,7 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*flags):
+def _bench(*flags, line=False):
+    """Runs bench.py; returns the COMPLETE record (bench.py --detail), or with line=True (the stdout line, the record)."""
+    import tempfile
+    detail = os.path.join(tempfile.mkdtemp(), "detail.json")
+    flags = tuple(flags) + ("--detail", detail)
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -23,14 +27,24 @@ def _bench(*flags):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     assert r.stdout.strip() == lines[0], r.stdout          # RCCL's banner and everything else must be on stderr
-    return json.loads(lines[0])
+    assert len(lines[0]) < 8000, len(lines[0])              # the driver keeps 8 KB of stdout
+    full = json.load(open(detail))
+    return (json.loads(lines[0]), full) if line else full
 
 
 def test_default_line_contract():
-    j = _bench("--batch", "8", "--cpu-items", "2")
+    ln, j = _bench("--batch", "8", "--cpu-items", "2", line=True)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in j, k
+        assert k in j and k in ln, k
+    assert ln["value"] == j["value"] and ln["roofline"]["frac"] == j["roofline"]["frac"] and ln["detail"] == "detail.json"
+    assert ln["cpu_baseline"]["cpu"] and ln["cpu_baseline"]["cores"] >= 1 and "bar" in ln["parity"]
+    assert all(v[1] is None or v[1] <= 1.0 for v in ln["kernels"].values())           # no bandwidth above the peak in the line
+    assert ln["value_literal_step"] > 0 and ln["ms_literal_step"] >= 0.5 * ln["ms_per_step"]          # (batch 8 is host-bound: both are the host's time)
+    assert 0 < j["roofline"]["frac_required"] <= j["roofline"]["frac"] + 1e-9
+    assert j["parity"]["all_items"]["items"] == 8 and j["parity"]["all_items"]["tri_id_mismatches"] == 0
+    a = j["parity"]["all_items"]
+    assert a["g_attr_max_abs_err"] <= 1e-5 * max(1.0, a["g_attr_max_abs"]) and a["g_pos_max_abs_err"] <= 1e-5 * max(1.0, a["g_pos_max_abs"])
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 2 and j["dtype"] == "f32"
     assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] < 1
     assert j["parity"]["tri_id_mismatches"] == 0
@@ -45,10 +59,19 @@ def test_default_run_carries_the_other_baseline_configs():
     """the run the driver records (no workload flags) also measures BASELINE configs[1], [2] and the [4]
     stand-in in the same process, each with per-kernel times, a roofline and a parity block of THAT workload at its full
     size -- against the reference itself (oracle/_ref travels with the tree)."""
-    j = _bench("--no-cpu-baseline")
+    ln, j = _bench("--no-cpu-baseline", line=True)
     assert j["config"]["batch_per_gpu"] == 64 and j["parity"]["tri_id_mismatches"] == 0
+    assert j["parity"]["all_items"]["items"] == 64 and j["parity"]["all_items"]["tri_id_mismatches"] == 0
     cf = j["configs"]
-    assert set(cf) == {"c2", "c3", "c5_standin"}
+    assert set(cf) == {"c2", "c3", "c5_standin", "dense", "s10k", "t1m", "t1m_shuffled"} == set(ln["configs"])
+    for name in ("dense", "s10k", "t1m", "t1m_shuffled"):            # the regimes the benchmark scene hides (VERDICT r3 item 1)
+        c = cf[name]
+        assert "error" not in c, c
+        assert c["parity"]["tri_id_mismatches"] == 0 and c["ms_per_step"] > 0 and "raster_fine" in c["kernels"]
+        assert ln["configs"][name]["ms"] == c["ms_per_step"] and ln["configs"][name]["par"]["ids"] == 0
+    assert cf["dense"]["coverage"] > 0.9 and cf["s10k"]["coverage"] > 0.9 and cf["t1m"]["triangles"] == 1000000
+    # index order must not matter much to a rasterizer with a bin stage (the reference's is O(T) either way)
+    assert cf["t1m_shuffled"]["kernels"]["raster_fine"]["avg_ms"] < 3 * cf["t1m"]["kernels"]["raster_fine"]["avg_ms"]
     for name in ("c2", "c3"):
         c = cf[name]
         assert "error" not in c, c

@@ -147,6 +147,23 @@ def test_operator_layer_uses_the_fused_gradient_only_when_it_is_legal(dr, oracle
     assert "interp_raster_grad" not in names and {"interp_grad", "raster_grad"} <= names, names
     within("after discard: g_pos", got["pos"].cpu().numpy(), gp2, grad_tol(gp2))
 
+    # (3b) set_fused_backward("auto") re-arms the contexts that had given up, and a gradient that was prepared but never
+    # collected -- the engine was asked for attr's gradient only -- neither blocks the next step nor stays alive
+    _plugin.set_fused_backward("auto")
+    names = _kernels(lib, _capi, lambda: got.update(zip(("pos", "attr"), step(ctx))))
+    assert "interp_raster_grad" in names and "raster_grad" not in names, names
+    pos_s = _t(b["pos"]).requires_grad_(True)
+    attr_s = _t(b["attr"]).requires_grad_(True)
+    rast_s, _ = dr.rasterize(ctx, pos_s, tri, res)
+    out_s, _ = dr.interpolate(attr_s, rast_s, tri)
+    (ga_only,) = torch.autograd.grad((out_s * _t(G)).sum(), [attr_s], retain_graph=True)        # the rasterize node never runs
+    assert rast_s._nvdr_origin.pending is not None
+    before = _plugin.fused_backward_count()
+    (out_s * _t(G)).sum().backward()                                                             # a full backward over the same graph
+    assert rast_s._nvdr_origin.pending is None and _plugin.fused_backward_count()["used"] == before["used"] + 1
+    within("after a stale prepared gradient: g_pos", pos_s.grad.cpu().numpy(), gp, grad_tol(gp))
+    within("after a stale prepared gradient: g_attr", ga_only.cpu().numpy(), ga, grad_tol(ga))
+
     # (4) another index buffer for the attributes: not this path's graph
     ctx2 = dr.RasterizeCudaContext()
     tri_b = _t(b["tri"].copy())

@@ -28,7 +28,8 @@ def _expected_flags(rast):
 
 @pytest.mark.parametrize("res,n,kind", [((512, 512), 3, "mesh"), ((100, 77), 2, "mesh"), ((8, 2056), 1, "mesh"), ((2100, 300), 1, "mesh"),
                                         ((256, 256), 2, "soup"), ((64, 64), 40, "mesh"), ((520, 1030), 2, "strip"),
-                                        ((520, 330), 45, "mesh"), ((64, 128), 1100, "mesh")])      # >= 2048 bins: with a work order
+                                        ((520, 330), 45, "mesh"), ((64, 128), 1100, "mesh"),        # >= 2048 bins: with a work order
+                                        ((64, 64), 4200, "mesh"), ((128, 192), 1500, "mesh")])      # > 4096 bins: the order made by two launches of several workgroups
 def test_flags_describe_the_rast_tensor(dr, res, n, kind):
     """Every in-image tile is written exactly once -- by the bin's own workgroup, by the workgroup that clears an empty bin
     for it, by the last part of a shared bin -- and says whether the tile shows a triangle (incl. >2048 px tiled viewports,
@@ -124,7 +125,7 @@ def test_consumers_skip_empty_tiles_only_for_the_untouched_rast(dr, oracle):
 
     # the same kernels with and without the flags give identical bits where no atomics are involved
     a = _plugin.interpolate_fwd(attr.detach(), rast.detach(), tri, tile_flags=flags)[0]
-    bb = _plugin.interpolate_fwd(attr.detach(), rast.detach(), tri)[0]
+    bb = _plugin.interpolate_fwd(attr.detach(), rast.detach(), tri, tile_flags=False)[0]
     assert torch.equal(a, bb)
 
     # an in-place edit: a triangle id painted into an empty tile
@@ -232,3 +233,87 @@ def test_views_of_the_rasterizers_outputs_are_ordinary_tensors(dr, oracle):
 def _plugin_counts():
     from nvdiffrast_amd.torch import _plugin
     return dict(_plugin.fused_backward_count())
+
+
+def test_the_plugin_finds_the_flags_itself(dr, oracle):
+    """INTEGRATION.md section 1's literal binding -- the reference's ops.py calling `_plugin.interpolate_fwd(attr, rast, tri)` and
+    friends with the reference's own argument lists -- gets the empty-tile skipping too: the record travels with the tensors
+    rasterize_fwd_cuda / interpolate_fwd* returned.  Observed through the verification mode, which counts (and
+    checks) every use of flags; a detached alias and autograd's copy of a saved output are recognised through the live owner."""
+    N, res = 2, (128, 192)
+    b = m10k_batch(N, seed=61, nx=20, ny=10, attrs=2)
+    pos_np = b["pos"].copy(); pos_np[..., :2] *= 0.6
+    rng = np.random.default_rng(3)
+    tex_np = rng.uniform(size=(1, 64, 64, 3)).astype(np.float32)
+    tri, pos, uvattr, tex = _t(b["tri"]), _t(pos_np), _t(b["uv"]), _t(tex_np)
+    state = _plugin.RasterizeCRStateWrapper(0)
+    no_ranges = torch.empty((0, 2), dtype=torch.int32)
+    mips = _plugin.texture_construct_mip(tex, -1, False)
+    _plugin.set_tile_flag_verification(True)
+    try:
+        n0 = _plugin.tile_flag_verifications()
+        rast, rast_db = _plugin.rasterize_fwd_cuda(state, pos, tri, res, no_ranges, -1)
+        uv, uv_da = _plugin.interpolate_fwd_da(uvattr, rast, tri, rast_db, True, [])
+        col = _plugin.texture_fwd_mip(tex, uv, uv_da, torch.tensor([]), mips, [], 3, 1)
+        topo = _plugin.antialias_construct_topology_hash(tri)
+        aa, work = _plugin.antialias_fwd(col, rast, pos, tri, topo)
+        dy = torch.randn_like(col)
+        g = _plugin.texture_grad_linear_mipmap_linear(tex, uv, dy, uv_da, torch.tensor([]), mips, [], 3, 1)
+        ga, gr, grdb = _plugin.interpolate_grad_da(uvattr, rast, tri, g[1], rast_db, g[2], True, [])
+        gp = _plugin.rasterize_grad_db(pos, tri, rast.detach(), gr, grdb)           # an alias of rast: found through its live owner
+        assert _plugin.tile_flag_verifications() - n0 == 1 + 2 + 1 + 2 + 1 + 1      # interpolate, texture (uv, uv_da), antialias, texture grad, interpolate grad, rasterize grad
+        # the same values as with the flags handed over explicitly and as without any
+        flags = state.last_flags
+        _plugin.set_tile_flag_verification(False)
+        uv_x, uvda_x = _plugin.interpolate_fwd_da(uvattr, rast, tri, rast_db, True, [], tile_flags=flags)
+        uv_n, uvda_n = _plugin.interpolate_fwd_da(uvattr, rast, tri, rast_db, True, [], tile_flags=False)
+        assert torch.equal(uv, uv_x) and torch.equal(uv, uv_n) and torch.equal(uv_da, uvda_n)
+        col_n = _plugin.texture_fwd_mip(tex, uv_n, uvda_n, torch.tensor([]), mips, [], 3, 1)    # no record on these
+        assert torch.equal(col, col_n)
+        ro, rdbo = oracle.rasterize(pos_np, b["tri"], res)
+        uvo, uvdao = oracle.interpolate(b["uv"], ro, b["tri"], rdbo, "all")
+        within("plugin-level flags: uv", uv.cpu().numpy(), uvo, ATOL)
+        gao, gro, grdbo = oracle.interpolate_grad(b["uv"], ro, b["tri"], g[1].cpu().numpy(), rdbo, g[2].cpu().numpy(), "all")
+        within("plugin-level flags: g_rast", gr.cpu().numpy(), gro, grad_tol(gro))
+        gpo = oracle.rasterize_grad(pos_np, b["tri"], ro, gr.cpu().numpy(), grdb.cpu().numpy())
+        within("plugin-level flags: g_pos", gp.cpu().numpy(), gpo, grad_tol(gpo))
+        # switched off altogether: nothing is looked up, nothing verified
+        _plugin.set_tile_flag_verification(True)
+        _plugin.set_tile_skipping(False)
+        n1 = _plugin.tile_flag_verifications()
+        uv_o, _ = _plugin.interpolate_fwd_da(uvattr, rast, tri, rast_db, True, [])
+        assert _plugin.tile_flag_verifications() == n1 and torch.equal(uv_o, uv)
+    finally:
+        _plugin.set_tile_skipping(True)
+        _plugin.set_tile_flag_verification(False)
+
+
+def test_verification_mode_catches_writes_the_version_counter_does_not_see(dr):
+    """The one deviation from the reference the flags carry: a write through `.data` (or an external kernel) leaves the
+    version counter alone, so the record stays valid and the consumers skip tiles that are no longer empty.  The verification
+    mode re-derives the flags from the tensor actually passed and refuses; `set_tile_skipping(False)` is the public way out."""
+    N, res = 1, (64, 64)
+    b = m10k_batch(N, seed=5, nx=10, ny=6)
+    pos_np = b["pos"].copy(); pos_np[..., :2] *= 0.4
+    ctx = dr.RasterizeCudaContext()
+    tri, attr = _t(b["tri"]), _t(b["attr"])
+    rast, _ = dr.rasterize(ctx, _t(pos_np), tri, res)
+    grid = _plugin.tile_flags_grid(rast._nvdr_origin.flags, N, *res)
+    e = torch.nonzero(grid[0] == 0)[0]
+    ty, tx = int(e[0]), int(e[1])
+    rast.data[0, ty * 8 + 2, tx * 8 + 2] = torch.tensor([0.2, 0.3, 0.0, 5.0], device="cuda")     # does not bump rast._version
+    painted = (0, ty * 8 + 2, tx * 8 + 2)
+    out_skipping, _ = dr.interpolate(attr, rast, tri)
+    assert float(out_skipping[painted].abs().max()) == 0.0                   # the hazard: the painted pixel is skipped
+    _plugin.set_tile_flag_verification(True)
+    try:
+        with pytest.raises(RuntimeError, match="tile flags disagree"):
+            dr.interpolate(attr, rast, tri)
+    finally:
+        _plugin.set_tile_flag_verification(False)
+    _plugin.set_tile_skipping(False)
+    try:
+        out_full, _ = dr.interpolate(attr, rast, tri)
+    finally:
+        _plugin.set_tile_skipping(True)
+    assert float(out_full[painted].abs().max()) > 0.0                        # read like any tensor, as the reference would

@@ -8,7 +8,7 @@ of summation alone moves it by 7e-5 of its value (tests/test_gpu_reference_direc
 import numpy as np
 import pytest
 import torch
-from conftest import ATOL, grad_tol, within
+from conftest import ATOL, BIG_SUM_FACTOR, discontinuous_pixels, grad_tol, within
 
 from nvdiffrast_amd.torch import _plugin
 from nvdiffrast_amd.utils import m10k_batch
@@ -65,10 +65,11 @@ def test_every_consumer_on_an_ordered_launch(dr, raw_oracle, n, res):
     within("ordered: g_col", _np(col.grad), g_col, grad_tol(g_col))
     g = oracle.texture_grad(tex_np, _np(uv), _np(col.grad), _np(uv_da), **kw)
     within("ordered: g_tex", _np(tex.grad), g["tex"], grad_tol(g["tex"]))
-    # (eight million pixels: a few sit on a mip-level boundary, where the f32 and the f64 evaluation of the footprint choose
-    # different sides and the level's gradient jumps -- 2 pixels in the first run of this test; one in a million is exempted)
-    within("ordered: g_uv", _np(uv.grad), g["uv"], grad_tol(g["uv"]), frac=1e-6)
-    within("ordered: g_uv_da", _np(uv_da.grad), g["uv_da"], grad_tol(g["uv_da"]), frac=1e-6)
+    # (eight million pixels: compared wherever the reference function is continuous within an ulp of uv / uv_da -- conftest.py)
+    ok = ~discontinuous_pixels(oracle, tex_np, _np(uv), _np(col.grad), _np(uv_da), kw)
+    assert (~ok).mean() <= 1e-4, (~ok).sum()
+    within("ordered: g_uv", _np(uv.grad), g["uv"], grad_tol(g["uv"]), where=ok)
+    within("ordered: g_uv_da", _np(uv_da.grad), g["uv_da"], grad_tol(g["uv_da"]), where=ok)
     ga, gr, grdb = oracle.interpolate_grad(uvattr, rh, b["tri"], _np(uv.grad), _np(rast_db), _np(uv_da.grad), "all")
     within("ordered: g_uvattr", _np(uva.grad), ga, grad_tol(ga))
     gp = oracle.rasterize_grad(b["pos"], b["tri"], rh, gr, grdb) + g_pos_aa
@@ -93,11 +94,11 @@ def test_separate_backward_kernels_on_an_ordered_launch(dr, raw_oracle):
     within("ordered, separate: g_attr", _np(g_attr), ga, grad_tol(ga))
     within("ordered, separate: g_rast", _np(g_rast), gr, grad_tol(gr))
     gp = oracle.rasterize_grad(b["pos"], b["tri"], rh, _np(g_rast))
-    within("ordered, separate: g_pos", _np(g_pos), gp, grad_tol(gp), frac=1e-4)      # (one element of 48 k at 1.04 of the bar in the first run)
+    within("ordered, separate: g_pos", _np(g_pos), gp, grad_tol(gp, BIG_SUM_FACTOR))      # (batch-scale sums: conftest.py)
     # and the same as the same kernels walking the image (no flags at all): only the order of the f32 atomics between blocks
     # differs, a tenth of the bar
-    a2, r2 = _plugin.interpolate_grad(_t(attr), rast, _t(b["tri"]), _t(dy))
-    p2 = _plugin.rasterize_grad(_t(b["pos"]), _t(b["tri"]), rast, g_rast)
+    a2, r2 = _plugin.interpolate_grad(_t(attr), rast, _t(b["tri"]), _t(dy), tile_flags=False)
+    p2 = _plugin.rasterize_grad(_t(b["pos"]), _t(b["tri"]), rast, g_rast, tile_flags=False)
     assert torch.equal(r2, g_rast)
     within("ordered vs image order: g_attr", _np(g_attr), _np(a2), 0.1 * grad_tol(ga))
     within("ordered vs image order: g_pos", _np(g_pos), _np(p2), 0.1 * grad_tol(gp))
@@ -146,8 +147,10 @@ def test_orders_without_a_second_part(dr, raw_oracle, case):
     within("degenerate order: g_col", _np(col.grad), g_col, grad_tol(g_col))
     g = oracle.texture_grad(tex_np, _np(uv), _np(col.grad), _np(uv_da), **kw)
     within("degenerate order: g_tex", _np(tex.grad), g["tex"], grad_tol(g["tex"], 2))     # eight million terms on a handful of texels
-    within("degenerate order: g_uv", _np(uv.grad), g["uv"], grad_tol(g["uv"]), frac=1e-6)
-    within("degenerate order: g_uv_da", _np(uv_da.grad), g["uv_da"], grad_tol(g["uv_da"]), frac=1e-6)
+    ok = ~discontinuous_pixels(oracle, tex_np, _np(uv), _np(col.grad), _np(uv_da), kw)
+    assert (~ok).mean() <= 1e-4, (~ok).sum()
+    within("degenerate order: g_uv", _np(uv.grad), g["uv"], grad_tol(g["uv"]), where=ok)
+    within("degenerate order: g_uv_da", _np(uv_da.grad), g["uv_da"], grad_tol(g["uv_da"]), where=ok)
     ga, gr, grdb = oracle.interpolate_grad(attr_np, rh, tri_np, _np(uv.grad), _np(rast_db), _np(uv_da.grad), "all")
     within("degenerate order: g_attr", _np(attr.grad), ga, grad_tol(ga, 2))
     gp = oracle.rasterize_grad(pos_np, tri_np, rh, gr, grdb) + g_pos_aa
