@@ -125,7 +125,7 @@ def algorithmic_bytes(graph, P, A, T, N):
             "interp_fwd": (16 + 4 * A) * P,                     # R rast, W out
             "interp_grad": (4 * A + 16 + 16) * P,               # R dy, R rast, W g_rast
             "raster_grad": 32 * P,                              # R g_rast 16 + R rast 16
-            "interp_raster_grad": (4 * A + 16 + 16) * P,        # fused backward as the operator layer runs it: R dy, R rast, W g_rast
+            "interp_raster_grad": (4 * A + 16) * P,             # fused backward as the operator layer runs it: R dy, R rast (g_rast is not written: ops._LazyGrad)
         }
         return per_kernel, (112 + 8 * A) * P
     C = 3
@@ -137,7 +137,7 @@ def algorithmic_bytes(graph, P, A, T, N):
         "aa_discontinuity": 16 * P,                             # R rast (ids)
         "tex_grad": (4 * C + 4 * A + 8 * A + 4 * A + 8 * A) * P,  # R dy, uv, uv_da; W g_uv, g_uv_da
         "interp_grad_da": (4 * A + 8 * A + 32 + 32) * P,        # R dy, dda, rast, rast_db; W g_rast, g_rast_db
-        "interp_raster_grad_da": (4 * A + 8 * A + 32 + 32) * P,  # the fused pair as the operator layer runs it: the same tensors once
+        "interp_raster_grad_da": (4 * A + 8 * A + 32) * P,      # the fused pair as the operator layer runs it: R dy, dda, rast, rast_db (g_rast, g_rast_db are not written)
         "raster_grad_db": 48 * P,                               # R g_rast, g_rast_db, rast
     }
     return per_kernel, 384 * P
@@ -155,7 +155,7 @@ def required_bytes(graph, P, A, T, N, cov, tile_cov):
             "interp_fwd": (16 * tile_cov + 4 * A) * P,
             "interp_grad": (4 * A * cov + 16 * tile_cov + 16) * P,
             "raster_grad": (16 * cov + 16 * tile_cov) * P,
-            "interp_raster_grad": (4 * A * cov + 16 * tile_cov + 16) * P,
+            "interp_raster_grad": (4 * A * cov + 16 * tile_cov) * P,
         }
         step = k["raster_fine"] + k["interp_fwd"] + k["interp_raster_grad"]
         return k, step
@@ -167,8 +167,8 @@ def required_bytes(graph, P, A, T, N, cov, tile_cov):
         "tex_fwd": (12 * A * tile_cov + 4 * C) * P,
         "aa_discontinuity": 16 * tile_cov * P,
         "tex_grad": (4 * C + 12 * A * tile_cov + 12 * A) * P,
-        "interp_grad_da": (12 * A * cov + 64 * tile_cov + 32) * P,
-        "interp_raster_grad_da": (12 * A * cov + 64 * tile_cov + 32) * P,
+        "interp_grad_da": (12 * A * cov + 32 * tile_cov + 32) * P,
+        "interp_raster_grad_da": (12 * A * cov + 32 * tile_cov) * P,
         "raster_grad_db": (32 * cov + 16 * tile_cov) * P,
     }
     step = (k["raster_fine"] + k["interp_fwd_da"] + k["tex_fwd"] + k["aa_discontinuity"] + 2 * 4 * C * P      # + antialias: out = color fwd, g_color = dy bwd

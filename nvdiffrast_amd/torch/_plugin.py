@@ -39,7 +39,7 @@ def set_cube_corner_fix(enable):
 # Fused backward of rasterize -> interpolate (ops.py `_RasterOrigin`): "auto" = prepare the position gradient inside
 # interpolate's backward kernel and use it when autograd shows that nothing else contributed to rast's gradient;
 # "off" = always the two separate kernels of the reference's structure.
-_fused = {"mode": "auto", "used": 0, "discarded": 0}
+_fused = {"mode": "auto", "used": 0, "discarded": 0, "materialized": 0}
 
 
 def set_fused_backward(mode):
@@ -64,9 +64,10 @@ def fused_backward_epoch():
 
 
 def fused_backward_count(what=None):
-    """Counts how often a prepared position gradient was used / discarded (tests); without argument returns both."""
+    """Counts how often a prepared position gradient was used / discarded, and how often the gradient of rast that the fused
+    kernel did not write had to be computed after all (tests); without argument returns all three."""
     if what is None:
-        return {"used": _fused["used"], "discarded": _fused["discarded"]}
+        return {"used": _fused["used"], "discarded": _fused["discarded"], "materialized": _fused["materialized"]}
     _fused[what] += 1
 
 

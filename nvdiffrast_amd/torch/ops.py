@@ -14,9 +14,11 @@ quirks -- they are listed where they occur, with the reference line they come fr
 ``tests/test_gpu_reference_ops.py`` runs the reference's own ``ops.py`` on ``_plugin`` next to this module.
 """
 import warnings
+import weakref
 
 import numpy as np
 import torch
+from torch.utils._pytree import tree_map as _tree_map
 
 from . import _plugin
 
@@ -104,18 +106,70 @@ class _Dispatch(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
+class _LazyGrad(torch.Tensor):
+    """The gradient of `rast` (or `rast_db`) that interpolate's backward returns when the fused kernel has already turned it into
+    the position gradient: a tensor whose VALUES are computed only if somebody looks at them.
+
+    In the graph rasterize -> interpolate the only reader of rast's gradient is rasterize's backward, and that one does not need
+    it any more (see _RasterOrigin) -- yet it is 16 B/pixel of stores (268 MB of the 297 MB the fused kernel wrote at the
+    headline batch), zeros for three quarters of them.  So the kernel does not write it, and autograd gets this stand-in: shape,
+    dtype and device of the real thing (a stride-0 view of one zero, so it has storage for the engine's stream bookkeeping), and
+    a __torch_dispatch__ that replaces it by the real gradient -- computed then by the reference's own two-kernel formulation,
+    interpolate_grad[_da] -- in front of ANY operation that touches it: autograd's summation when rast's gradient has other
+    contributors, the clone of retain_grad(), a hook, arithmetic on what autograd.grad(..., inputs=[rast]) hands out.  Whoever
+    looks sees the reference's values; the price is paid by those who look.  (What no dispatch can see: raw `.data_ptr()` access
+    to this object from user code -- it points at a single zero.)"""
+
+    @staticmethod
+    def __new__(cls, like, source, index):
+        key = (like.device, like.dtype)
+        zero = _LazyGrad._zeros.get(key)
+        if zero is None:
+            zero = _LazyGrad._zeros[key] = torch.zeros((), dtype=like.dtype, device=like.device)
+        r = torch.Tensor._make_subclass(cls, zero.expand(like.shape), False)
+        r._source, r._index = source, index
+        return r
+
+    def materialize(self):
+        return self._source.get()[self._index]
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        real = lambda t: t.materialize() if isinstance(t, _LazyGrad) else t          # noqa: E731
+        return func(*_tree_map(real, args), **_tree_map(real, kwargs or {}))
+
+
+_LazyGrad._zeros = {}
+
+
+class _LazySource:
+    """Computes the real gradients behind one or two _LazyGrad objects, once, on first use; drops its inputs afterwards."""
+    __slots__ = ("thunk", "values")
+
+    def __init__(self, thunk):
+        self.thunk, self.values = thunk, None
+
+    def get(self):
+        if self.values is None:
+            self.values, self.thunk = self.thunk(), None
+            _plugin.fused_backward_count("materialized")
+        return self.values
+
+
 class _RasterOrigin:
     """What a `rast` tensor remembers about the rasterize call that produced it, for the fused backward pass.
 
     The metric's graph is rasterize -> interpolate.  Its backward is two kernels over the same pixels; the library has
     one kernel that does both (csrc/backward_fused.hip, `_plugin.interpolate_rasterize_grad`).  Whether the fused result
     may be USED is only known when autograd delivers rast's gradient to the rasterize node: if interpolate was the sole
-    contributor, the tensor that arrives is the very g_rast interpolate returned (same storage, same version counter);
-    if anything else contributed (antialias does not, but user code such as a mask made from rast does), autograd has
-    summed the contributions into another tensor.  So interpolate's backward computes g_attr, g_rast AND the position
-    gradient in one pass, returns g_rast as usual -- always a correct gradient -- and leaves the position gradient here;
-    rasterize's backward takes it when the tensor it receives is that g_rast, and otherwise computes the gradient from
-    what it did receive, as if nothing had been prepared (the context then stops preparing: `fused_disabled`)."""
+    contributor, the object that arrives is the very g_rast interpolate returned; if anything else contributed (antialias does
+    not, but user code such as a mask made from rast does), autograd has summed the contributions into another tensor.  So
+    interpolate's backward computes g_attr AND the position gradient in one pass, returns as g_rast a stand-in that computes
+    the real values only if somebody looks at them (_LazyGrad: the fused kernel does not write g_rast) -- always a correct
+    gradient -- and leaves the position gradient here; rasterize's backward takes it when the object it receives is that
+    stand-in, and otherwise computes the gradient from what it did receive, as if nothing had been prepared (the context then
+    stops preparing: `fused_disabled`).  `pending` refers to the stand-ins weakly: a backward pass that never reaches the
+    rasterize node (autograd.grad(..., inputs=[attr])) leaves nothing behind that pins the upstream gradient."""
     __slots__ = ("pos", "tri", "state", "rast_ptr", "rast_version", "rast_shape", "db_ptr", "db_version", "grad_db",
                  "interpolations", "pending", "flags")
 
@@ -124,7 +178,7 @@ class _RasterOrigin:
         self.rast_ptr, self.rast_version, self.rast_shape = rast.data_ptr(), rast._version, tuple(rast.shape)
         self.db_ptr, self.db_version, self.grad_db = rast_db.data_ptr(), rast_db._version, bool(grad_db)
         self.interpolations = 0            # interpolate() calls that took this rast
-        self.pending = None                # (g_rast, its data_ptr, its version, g_pos) between the two backward nodes
+        self.pending = None                # (weak ref to the g_rast stand-in, g_pos, weak ref to the g_rast_db stand-in or None) between the two backward nodes
         self.flags = flags                 # tile occupancy of this rast (one byte per 8x8 tile), written by the rasterizer
 
     def flags_for(self, rast):
@@ -195,13 +249,13 @@ class _RasterizeOp:
         grad_db, origin = state
         pos, tri, rast = saved
         if origin is not None and origin.pending is not None:
-            (g_rast, ptr, version, g_pos, g_db), origin.pending = origin.pending, None
-            # the prepared gradient stands if what arrives for rast is interpolate's own g_rast and what arrives for rast_db is
-            # nothing (plain interpolation), irrelevant (grad_db=False) or interpolate's own g_rast_db
-            db_ok = (d_rast_db is None and g_db is None) or not grad_db or \
-                    (g_db is not None and d_rast_db is not None and d_rast_db.data_ptr() == g_db[1] and d_rast_db._version == g_db[2])
-            if (d_rast is not None and db_ok
-                    and d_rast.data_ptr() == ptr and d_rast._version == version and d_rast.shape == g_rast.shape):
+            (lz_rast, g_pos, lz_db), origin.pending = origin.pending, None
+            lz_rast, lz_db = lz_rast(), (None if lz_db is None else lz_db())
+            # the prepared gradient stands if what arrives for rast is interpolate's own (unwritten) g_rast -- the very object:
+            # nobody added to it, no hook replaced it -- and what arrives for rast_db is nothing (plain interpolation),
+            # irrelevant (grad_db=False) or interpolate's own g_rast_db
+            db_ok = (d_rast_db is None and lz_db is None) or not grad_db or (lz_db is not None and d_rast_db is lz_db)
+            if d_rast is not None and d_rast is lz_rast and db_ok:
                 _plugin.fused_backward_count("used")
                 return None, g_pos, None, None, None, None, None
             # rast's gradient has other contributors in this program: what was prepared is void, and preparing it again
@@ -211,6 +265,10 @@ class _RasterizeOp:
                 _plugin._log_info("fused rasterize/interpolate backward switched off on this context: rast's gradient has other "
                                   "contributors (set_fused_backward('auto') re-arms it)")
             origin.state.fused_disabled = _plugin.fused_backward_epoch()
+        if isinstance(d_rast, _LazyGrad):
+            d_rast = d_rast.materialize()
+        if isinstance(d_rast_db, _LazyGrad):
+            d_rast_db = d_rast_db.materialize()
         if d_rast is None:
             if not grad_db:
                 return (None,) * 7
@@ -256,8 +314,11 @@ class _InterpolateOp:
             origin.pending = None          # left over from a backward pass that never reached the rasterize node
             #                                (autograd.grad(inputs=[attr]), an exception): void, and must not block or pin memory
         if origin is not None and origin.usable_by(attr, rast, tri):
-            g_attr, g_rast, _, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, tile_flags=flags)
-            origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos, None)
+            g_attr, _, _, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, with_g_rast=False, tile_flags=flags)
+            # g_rast itself is not written: autograd gets a stand-in that computes it if anybody looks (_LazyGrad)
+            source = _LazySource(lambda: (_plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)[1],))
+            g_rast = _LazyGrad(rast, source, 0)
+            origin.pending = (weakref.ref(g_rast), g_pos, None)
             return g_attr, g_rast
         return _plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)
 
@@ -277,11 +338,13 @@ class _InterpolateOp:
                 origin.pending = None      # (stale, as in _plain_grad)
             if origin is not None and origin.usable_by(attr, rast, tri, rast_db):
                 # config 3's pair: interpolate_grad_da + rasterize_grad_db in one pass (see _RasterOrigin)
-                g_attr, g_rast, g_rast_db, g_pos = _plugin.interpolate_rasterize_grad(
-                    attr, rast, tri, origin.pos, d_out, tile_flags=flags, rast_db=rast_db, dda=d_out_da,
+                g_attr, _, _, g_pos = _plugin.interpolate_rasterize_grad(
+                    attr, rast, tri, origin.pos, d_out, with_g_rast=False, tile_flags=flags, rast_db=rast_db, dda=d_out_da,
                     diff_attrs_all=diff_all, diff_attrs_vec=diff_list, db_to_pos=origin.grad_db)
-                origin.pending = (g_rast, g_rast.data_ptr(), g_rast._version, g_pos,
-                                  (g_rast_db, g_rast_db.data_ptr(), g_rast_db._version))
+                source = _LazySource(lambda: _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
+                                                                         tile_flags=flags)[1:])
+                g_rast, g_rast_db = _LazyGrad(rast, source, 0), _LazyGrad(rast_db, source, 1)
+                origin.pending = (weakref.ref(g_rast), g_pos, weakref.ref(g_rast_db))
                 return g_attr, g_rast, None, g_rast_db, None, None
             g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
                                                                     tile_flags=flags)

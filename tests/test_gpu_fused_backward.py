@@ -139,6 +139,7 @@ def test_operator_layer_uses_the_fused_gradient_only_when_it_is_legal(dr, oracle
     names = _kernels(lib, _capi, lambda: got.update(zip(("pos", "attr"), step(ctx, extra))))
     assert "interp_raster_grad" in names and "raster_grad" in names, names                 # prepared, discarded, recomputed
     assert _plugin.fused_backward_count()["discarded"] == before["discarded"] + 1
+    assert _plugin.fused_backward_count()["materialized"] == before["materialized"] + 1   # autograd's sum looked at the unwritten g_rast
     within("discarded fused: g_pos", got["pos"].cpu().numpy(), gp2, grad_tol(gp2))
     within("discarded fused: g_attr", got["attr"].cpu().numpy(), ga, grad_tol(ga))
 
@@ -163,6 +164,39 @@ def test_operator_layer_uses_the_fused_gradient_only_when_it_is_legal(dr, oracle
     assert rast_s._nvdr_origin.pending is None and _plugin.fused_backward_count()["used"] == before["used"] + 1
     within("after a stale prepared gradient: g_pos", pos_s.grad.cpu().numpy(), gp, grad_tol(gp))
     within("after a stale prepared gradient: g_attr", ga_only.cpu().numpy(), ga, grad_tol(ga))
+
+    # (3c) the fused kernel does not write g_rast: autograd carries a stand-in that computes it when somebody looks (ops._LazyGrad).
+    # Nobody looked in (1); the summation in (2) did; so do retain_grad(), a hook, and autograd.grad(..., inputs=[rast]) -- and what
+    # they see is the reference's g_rast, while the position gradient still comes from the fused kernel where that is legal.
+    def graph():
+        pos = _t(b["pos"]).requires_grad_(True)
+        attr = _t(b["attr"]).requires_grad_(True)
+        rast, _ = dr.rasterize(ctx, pos, tri, res)
+        out, _ = dr.interpolate(attr, rast, tri)
+        return pos, attr, rast, (out * _t(G)).sum()
+    before = _plugin.fused_backward_count()
+    pos_r, attr_r, rast_r, loss = graph()
+    rast_r.retain_grad()
+    loss.backward()
+    after = _plugin.fused_backward_count()
+    assert after["used"] == before["used"] + 1 and after["materialized"] == before["materialized"] + 1
+    within("retain_grad on rast: g_rast", rast_r.grad.cpu().numpy(), gr, grad_tol(gr))
+    within("retain_grad on rast: g_pos", pos_r.grad.cpu().numpy(), gp, grad_tol(gp))
+    pos_r, attr_r, rast_r, loss = graph()
+    g_rast_user, g_pos_user = torch.autograd.grad(loss, [rast_r, pos_r])
+    assert _plugin.fused_backward_count()["used"] == after["used"] + 1
+    within("autograd.grad w.r.t. rast: g_rast", (g_rast_user * 1.0).cpu().numpy(), gr, grad_tol(gr))
+    within("autograd.grad w.r.t. rast: g_rast (numpy)", g_rast_user.cpu().numpy(), gr, grad_tol(gr))
+    within("autograd.grad w.r.t. rast: g_pos", g_pos_user.cpu().numpy(), gp, grad_tol(gp))
+    pos_r, attr_r, rast_r, loss = graph()
+    seen = []
+    rast_r.register_hook(lambda g: seen.append(g.detach().clone()) or g * 2.0)                 # a hook that looks AND replaces
+    before = _plugin.fused_backward_count()
+    loss.backward()
+    assert _plugin.fused_backward_count()["discarded"] == before["discarded"] + 1              # twice the gradient: not the prepared one
+    within("hook on rast: g_rast seen", seen[0].cpu().numpy(), gr, grad_tol(gr))
+    within("hook on rast: g_pos", pos_r.grad.cpu().numpy(), 2.0 * gp, grad_tol(2.0 * gp))
+    _plugin.set_fused_backward("auto")                                                          # (the hook step made the context give up)
 
     # (4) another index buffer for the attributes: not this path's graph
     ctx2 = dr.RasterizeCudaContext()
