@@ -10,6 +10,7 @@
 //                 (vertex, attribute) per block.
 #include "nvdr_device.hpp"
 #include "nvdr_host.hpp"
+#include <type_traits>
 
 namespace nvdr {
 
@@ -141,6 +142,67 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
         }
         outDA[i] = make_float2(dsdx, dsdy);
     }
+    }
+}
+
+// The forward pass without pixel differentials, for vector-sized attribute rows (A = 4 or 2).  A pixel is a chain of dependent
+// loads -- flag -> rast -> triangle -> three vertices -- and the launch is bound by how many of those chains are in flight, not
+// by bytes (one pixel per thread: 83 us for 340 MB at the headline batch).  Here a thread owns K pixels of one column and walks
+// the chain in stages, K loads wide: K rast loads, then K index triples, then 3K attribute rows, then K stores.  No branches in
+// between (a pixel without a triangle, or beyond the image, reads row 0 of the respective table instead and its result is
+// discarded), so that every stage's loads are issued back to back.
+// Workgroup = 64 x 4K pixels, wave w = rows [wK, wK + K): one 8-pixel tile row (K divides 8), so ONE occupancy flag per lane.
+template <int A_CT, int K>
+__global__ __launch_bounds__(256) void k_interp_fwd_cols(const InterpParams p, int gx, int gy)
+{
+    static_assert(A_CT == 4 || A_CT == 2, "vector rows only");
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "K rows of one tile row");
+    typedef typename std::conditional<A_CT == 4, float4, float2>::type Row;
+    int bx, by, pz;
+    if (p.ordered ? !decode_block_ordered(p.flags, gx, gy, 64, 4 * K, bx, by, pz) : !decode_block(gx, gy, p.depth, bx, by, pz)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = bx * 64 + lane, y0 = by * (4 * K) + wave * K;
+    if (x >= p.width || y0 >= p.height) return;
+    const bool empty = p.flags.empty(pz, y0, x);
+    const size_t pix0 = ((size_t)pz * p.height + y0) * p.width + x;
+    const size_t voff = (p.instance_mode && !p.attrBC) ? (size_t)pz * p.numVertices : 0;
+    const Row* rows = (const Row*)p.attr + voff;
+
+    float4 r[K];
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        r[k] = ((const float4*)p.rast)[(!empty && y0 + k < p.height) ? pix0 + (size_t)k * p.width : 0];
+    int vi[K][3];
+    bool valid[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int t = float_to_triidx(r[k].w) - 1;
+        valid[k] = !empty && y0 + k < p.height && t >= 0 && t < p.numTriangles;
+        const int* tp = p.tri + (valid[k] ? t : 0) * 3;
+        vi[k][0] = tp[0]; vi[k][1] = tp[1]; vi[k][2] = tp[2];
+    }
+    Row a[K][3];
+    bool keep[K];                                           // false: corrupt indices, the pixel is left untouched (interpolate.cu:54-58)
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const bool ok = indices_ok(vi[k][0], vi[k][1], vi[k][2], p.numVertices);
+        keep[k] = !valid[k] || ok;
+        valid[k] = valid[k] && ok;
+#pragma unroll
+        for (int j = 0; j < 3; j++) a[k][j] = rows[valid[k] ? vi[k][j] : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (y0 + k >= p.height || !keep[k]) continue;
+        const float b0 = valid[k] ? r[k].x : 0.f, b1 = valid[k] ? r[k].y : 0.f, b2 = valid[k] ? 1.f - r[k].x - r[k].y : 0.f;
+        Row* out = (Row*)p.out + pix0 + (size_t)k * p.width;
+        if constexpr (A_CT == 4) {
+            const float4 o = make_float4(b0 * a[k][0].x + b1 * a[k][1].x + b2 * a[k][2].x, b0 * a[k][0].y + b1 * a[k][1].y + b2 * a[k][2].y,
+                                         b0 * a[k][0].z + b1 * a[k][1].z + b2 * a[k][2].z, b0 * a[k][0].w + b1 * a[k][1].w + b2 * a[k][2].w);
+            if (p.streamOut) store_streaming(out, o); else *out = o;
+        } else {
+            *out = make_float2(b0 * a[k][0].x + b1 * a[k][1].x + b2 * a[k][2].x, b0 * a[k][0].y + b1 * a[k][1].y + b2 * a[k][2].y);
+        }
     }
 }
 
@@ -425,9 +487,25 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
     p.ordered = (p.flags.order && enable_da) ? 1 : 0;
     if (p.ordered) grid = dim3((unsigned)tile_flags_ordered_grid(p.flags, 16 / ip_fwd_pixels(enable_da)));
     const float* VECPTR = out;
+    const bool vecA = (A == 4 && !((uintptr_t)attr & 15) && !((uintptr_t)out & 15)) || (A == 2 && !((uintptr_t)attr & 7) && !((uintptr_t)out & 7));
     {
         ProfileScope ps(enable_da ? "interp_fwd_da" : "interp_fwd", stream);
         if (enable_da) NVDR_DISPATCH_A(k_interp_fwd, true, grid, block, 0, stream, p);
+        else if (vecA && tune_int("NVDR_TUNE_IPFWD_K", 4) > 0) {
+            // vector rows: K pixels per thread, staged (k_interp_fwd_cols), along the work order where there is one.  Headline batch /
+            // dense scene, us (r04n): one pixel per thread in image order 92 / 130; K = 1: 113 / 145 (ordered 102 / 141); K = 2: 97 / 121
+            // (86 / 122); K = 4: 92 / 115 (83 / 117); K = 8: 91 / 119 (81 / 117).  For comparison, torch's copy of the dense
+            // scene's 537 MB takes 100 us on these boxes (tools/write_bw.py: 5.35 TB/s read + written).
+            const int K = tune_int("NVDR_TUNE_IPFWD_K", 4);
+            p.ordered = (p.flags.order && tune_int("NVDR_TUNE_IPFWD_ORDERED", 1)) ? 1 : 0;
+            const int gx = (W + 63) / 64, gy = (H + 4 * K - 1) / (4 * K);
+            const long long total = p.ordered ? tile_flags_ordered_grid(p.flags, 16 / K) : (long long)gx * gy * N;
+            NVDR_REQUIRE(total < (1ll << 30), "interpolate_fwd: too many pixel blocks");
+            const dim3 cgrid((unsigned)(((total + 7) / 8) * 8));
+#define NVDR_IPFWD(KK) do { if (A == 4) hipLaunchKernelGGL((k_interp_fwd_cols<4, KK>), cgrid, block, 0, stream, p, gx, gy);   \
+                            else        hipLaunchKernelGGL((k_interp_fwd_cols<2, KK>), cgrid, block, 0, stream, p, gx, gy); } while (0)
+            if (K == 1) NVDR_IPFWD(1); else if (K == 2) NVDR_IPFWD(2); else if (K == 8) NVDR_IPFWD(8); else NVDR_IPFWD(4);
+        }
         else           NVDR_DISPATCH_A(k_interp_fwd, false, grid, block, 0, stream, p);
     }
     NVDR_LAUNCH_CHECK();

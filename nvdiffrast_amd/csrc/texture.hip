@@ -1106,6 +1106,225 @@ __global__ __launch_bounds__(256, 8) void k_tex_grad_light(const TexParams p)
     }
 }
 
+// The same pass with ONE WAVE per 16x16-pixel block (compile-time channel counts): the wave walks the block's four 8x8 tiles in
+// stages -- four flags, then the four tiles' upstream gradients (4 x C loads in flight per lane instead of C), then, only
+// for tiles that need them, uv / uv_da -- and votes on the block by itself: no LDS, no barrier.  The kernel above is bound by
+// its chain of dependent loads with one tile per wave (0.33 ms for 1.05 GB at config 3, 3 TB/s); this form has four times the
+// bytes in flight per wave at the same occupancy.  A workgroup is four waves = four blocks side by side (64 x 16 pixels).
+// Records, zero stores and uv gradients are those of the kernel above, tile for tile (record number = block * 4 + tile).
+template <int FILTER, int C>
+__global__ __launch_bounds__(256, 8) void k_tex_grad_light_w(const TexParams p, int gx4, int exp)
+{
+    int bx4, by, pz;
+    if (!decode_block(gx4, p.tilesY, p.n, bx4, by, pz)) return;
+    const int lane = threadIdx.x & 63;
+    const int bx = bx4 * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (bx >= p.tilesX) return;
+    const int blk = (pz * p.tilesY + by) * p.tilesX + bx;
+    const int tz = (p.texDepth == 1) ? 0 : pz;
+    const int px0 = bx * 16 + (lane & 7), py0 = by * 16 + (lane >> 3);
+    // Pixel numbers fit 32 bits here and so do their byte offsets into every per-pixel tensor (the host checks: 16 bytes per
+    // pixel at most), so every access is base pointer + one 32-bit lane offset.  This kernel is bound by its instruction count
+    // -- a streaming pass over 33 M pixels pays 0.85 us per vector instruction per wave of pixels at config 3 -- and 64-bit
+    // index arithmetic, per-tile wave reductions and per-lane copies of wave-uniform values were most of the 1000 it had.
+    const uint32_t pidx0 = (uint32_t)px0 + (uint32_t)p.imgW * ((uint32_t)py0 + (uint32_t)p.imgH * (uint32_t)pz);
+    auto pix = [&](int t) { return pidx0 + (uint32_t)((t & 1) * 8) + (uint32_t)((t >> 1) * 8) * (uint32_t)p.imgW; };
+    auto at = [](const void* base, uint32_t bytes) { return (const char*)base + bytes; };
+
+    bool inside[4], ztile[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) inside[t] = px0 + (t & 1) * 8 < p.imgW && py0 + (t >> 1) * 8 < p.imgH;
+    float d[4][C];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const float* pDy = (const float*)at(p.dy, (inside[t] ? pix(t) : 0u) * (uint32_t)(4 * C));   // (a pixel beyond the image reads pixel 0's and ignores it)
+#pragma unroll
+        for (int c = 0; c < C; c++) d[t][c] = pDy[c];
+    }
+    {
+        // the block's four flags: two bytes in each of two rows of the flag array, each pair inside one dword (the block's first
+        // tile column is even; the array is 16-byte aligned and padded) -- two scalar loads in flight together
+        const int tx8 = bx * 2, ty8 = by * 2;
+        uint32_t w0 = 0x01010101u, w1 = 0x01010101u;                               // (no flags, or beyond the array: "not empty")
+        const bool haveF = p.zflags.f != nullptr && tx8 < p.zflags.w;
+        const size_t f0 = ((size_t)pz * p.zflags.h + ty8) * p.zflags.w + tx8, f1 = f0 + p.zflags.w;
+        const bool row0 = haveF && ty8 < p.zflags.h, row1 = haveF && ty8 + 1 < p.zflags.h;
+        const uint32_t* wp0 = (const uint32_t*)p.zflags.f + (f0 >> 2);
+        const uint32_t* wp1 = (const uint32_t*)p.zflags.f + (f1 >> 2);
+        if (row0) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(w0) : "s"(wp0) : "memory");
+        if (row1) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(w1) : "s"(wp1) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1) :: "memory");
+        const uint32_t s0 = (uint32_t)(f0 & 3) * 8u, s1 = (uint32_t)(f1 & 3) * 8u;
+        const bool col1 = tx8 + 1 < p.zflags.w;
+        ztile[0] = row0 && ((w0 >> s0) & 0xFFu) == 0u;
+        ztile[1] = row0 && col1 && ((w0 >> (s0 + 8u)) & 0xFFu) == 0u;
+        ztile[2] = row1 && ((w1 >> s1) & 0xFFu) == 0u;
+        ztile[3] = row1 && col1 && ((w1 >> (s1 + 8u)) & 0xFFu) == 0u;
+        if (haveF && (p.zflags.w & 1)) {                                           // odd row length: a pair may straddle two dwords -- byte by byte
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int x8 = tx8 + (t & 1), y8 = ty8 + (t >> 1);
+                ztile[t] = x8 < p.zflags.w && y8 < p.zflags.h && p.zflags.f[((size_t)pz * p.zflags.h + y8) * p.zflags.w + x8] == 0;
+            }
+        }
+    }
+    uint64_t am[4];
+    uint32_t fin = 0u;                                                             // OR of the magnitudes' exponent tests
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        uint32_t dmax = 0u;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            if (!inside[t]) d[t][c] = 0.f;
+            dmax |= (uint32_t)__float_as_int(d[t][c]);
+            fin = max(fin, (uint32_t)__float_as_int(d[t][c]) & 0x7FFFFFFFu);       // >= 0x7F800000: inf or NaN
+        }
+        am[t] = __ballot((dmax << 1) != 0u);                                      // some channel is not +-0
+    }
+    bool light = __ballot(fin >= 0x7F800000u) == 0ull;
+    // tiles whose pixels are all active: the uniform-wave test of k_tex_grad (uv / uv_da only where the flags do not already say zero)
+    float2 uvt[4];
+    float4 dat[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        uvt[t] = make_float2(0.f, 0.f); dat[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (am[t] == ~0ull && !ztile[t]) {
+            uvt[t] = *(const float2*)at(p.uv, pix(t) * 8u);
+            if (FILTER != TEX_LINEAR) dat[t] = *(const float4*)at(p.uvDA, pix(t) * 16u);
+        }
+    }
+    int su[4], sv[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        su[t] = __builtin_amdgcn_readfirstlane(__float_as_int(uvt[t].x)); sv[t] = __builtin_amdgcn_readfirstlane(__float_as_int(uvt[t].y));
+        if (am[t] == 0ull || ztile[t]) continue;                                  // (a flagged tile's uv is zero by construction)
+        if (am[t] != ~0ull) { light = false; continue; }
+        bool same = (__float_as_int(uvt[t].x) == su[t]) & (__float_as_int(uvt[t].y) == sv[t]);
+        if (FILTER != TEX_LINEAR) {
+            same &= (dat[t].x == 0.f) & (dat[t].y == 0.f) & (dat[t].z == 0.f) & (dat[t].w == 0.f);
+            if (p.bias) same &= !(fabsf(*(const float*)at(p.bias, pix(t) * 4u)) == INFINITY);
+        }
+        if (__ballot(same) != ~0ull) light = false;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) if (am[t] != 0ull && am[t] != ~0ull) light = false;    // (a partly active tile, flagged or not)
+    if (FILTER != TEX_LINEAR && p.bias) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)                                               // flagged tiles: the bias may still be infinite (-inf + inf)
+            if (light && am[t] == ~0ull && ztile[t] && __ballot(fabsf(*(const float*)at(p.bias, pix(t) * 4u)) == INFINITY) != 0ull) light = false;
+    }
+    if (lane == 0) p.heavy[blk] = light ? 0 : 1;
+    if (!light) return;
+
+    auto store_out = [&](int t, float2 g) {
+        if ((exp & 1) && g.x != 12345.f) return;
+        *(float2*)at(p.gradUV, pix(t) * 8u) = g;
+        if (FILTER == TEX_LML) {
+            if (p.gradBias) *(float*)at(p.gradBias, pix(t) * 4u) = 0.f;
+            if (p.gradUVDA) *(float4*)at(p.gradUVDA, pix(t) * 16u) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if ((am[0] | am[1] | am[2] | am[3]) == 0ull) {
+        // no upstream gradient anywhere in the block: explicit zeros (texture_kernel.cu:922-971)
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (inside[t]) store_out(t, make_float2(0.f, 0.f));
+        return;
+    }
+
+    // The constant quad: texel indices, weights, and per channel the two texel differences the uv gradient needs.  Wave-uniform
+    // throughout: the texels come through scalar loads, and the quad is recomputed only when a tile's uv differs from its
+    // predecessor's (a background's tiles all sample one place).
+    const float* pIn0 = p.tex[0];
+    const float sclu0 = (float)p.texW, sclv0 = (float)p.texH;
+    int qu = 0, qv = 0, qtc[4] = {-1, -1, -1, -1};
+    float qw[4] = {0.f, 0.f, 0.f, 0.f}, xu[C], xv[C];
+    bool have = false;
+    auto quad_for = [&](int u, int v) {
+        if (have && u == qu && v == qv) return;
+        have = true; qu = u; qv = v;
+        const Quad q0 = tex_index_linear(p, __int_as_float(u), __int_as_float(v), tz, 0);
+        const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
+        qw[0] = w000; qw[1] = w010; qw[2] = w001; qw[3] = w011;
+        float qa[4][C];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            qtc[k] = __builtin_amdgcn_readfirstlane(q0.tc[k]);
+#pragma unroll
+            for (int c = 0; c < C; c++) qa[k][c] = 0.f;
+            if (qtc[k] >= 0) {
+                const float* tp = pIn0 + (size_t)qtc[k] * C;                       // wave-uniform address: scalar loads
+#pragma unroll
+                for (int c = 0; c < C; c++) asm volatile("s_load_dword %0, %1, %2" : "=s"(qa[k][c]) : "s"(tp), "n"(c * 4) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < C; c++) asm volatile("" : "+s"(qa[k][c]));          // (every use of the loaded values stays behind the wait)
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float ad = (qa[3][c] + qa[0][c] - qa[1][c] - qa[2][c]);
+            xu[c] = (qa[1][c] - qa[0][c]) + q0.fv * ad;
+            xv[c] = (qa[2][c] - qa[0][c]) + q0.fu * ad;
+        }
+    };
+    // one record, one word per lane, in ONE store: words 0..3 texel indices (a record whose FIRST tap has no texel -- boundary mode
+    // zero -- is stored with the first valid tap moved to the front; -1 in word 0 = no tap has one), 4..7 weights, 8.. the summed
+    // upstream gradient per channel
+    auto put_record = [&](int slot, const float* tot) {
+        int first = qtc[0], fk = 0;
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (first < 0 && qtc[k] >= 0) { first = qtc[k]; fk = k; }
+        int word = first;
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (lane == k) word = (fk == k) ? -1 : qtc[k];
+        if (lane == 4) word = __float_as_int(fk == 0 ? qw[0] : fk == 1 ? qw[1] : fk == 2 ? qw[2] : qw[3]);
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (lane == 4 + k) word = __float_as_int(qw[k]);
+#pragma unroll
+        for (int c = 0; c < C; c++) if (lane == kTexRecHeader + c) word = __float_as_int(tot[c]);
+        if (lane < kTexRecHeader + C) p.rec[(size_t)lane * p.nrec + slot] = word;
+    };
+    auto grad_of = [&](int t) {
+        float2 g = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < C; c++) { g.x += d[t][c] * xu[c] * sclu0; g.y += d[t][c] * xv[c] * sclv0; }
+        return g;
+    };
+
+    const bool oneQuad = (am[0] & am[1] & am[2] & am[3]) == ~0ull && su[1] == su[0] && su[2] == su[0] && su[3] == su[0]
+                                                                  && sv[1] == sv[0] && sv[2] == sv[0] && sv[3] == sv[0];
+    if (oneQuad && !(exp & 4)) {
+        // the whole block samples one place (the rule in a background): ONE record for its 256 pixels, in the first tile's slot
+        // (the other three stay "no record", as the host initialised them)
+        quad_for(su[0], sv[0]);
+        float tot[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            tot[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_last((d[0][c] + d[1][c]) + (d[2][c] + d[3][c]))), 63));
+        put_record(blk * 4, tot);
+#pragma unroll
+        for (int t = 0; t < 4; t++) store_out(t, grad_of(t));
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (!inside[t]) continue;
+        float2 g = make_float2(0.f, 0.f);
+        if (am[t] != 0ull && !(exp & 4)) {
+            // uniform tile (all 64 pixels active, hence inside): as in k_tex_grad, with the totals leaving as a record
+            quad_for(su[t], sv[t]);
+            float tot[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) tot[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_last(d[t][c])), 63));
+            put_record(blk * 4 + t, tot);
+            g = grad_of(t);
+        }
+        store_out(t, g);
+    }
+}
+
 // Second level of the gradient reduction for constant-uv regions: merges the per-wave records of k_tex_grad (TexParams::rec)
 // and adds the totals to level 0 of the gradient texture.  One wave takes kFoldPerWave consecutive records, each lane
 // kFoldPerLane of them (strided by 64, so every load instruction is coalesced; all loads of a lane are independent and in
@@ -1688,7 +1907,22 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
         else if (C == 4) hipLaunchKernelGGL((k_tex_grad_light<FILTER, 4>), gridL, dim3(256), 0, stream, p);          \
         else             hipLaunchKernelGGL((k_tex_grad_light<FILTER, 0>), gridL, dim3(256), 0, stream, p);          \
     } while (0)
-            if (filter_mode == TEX_LINEAR) NVDR_TEX_LIGHT(TEX_LINEAR);
+            const int gx4 = (p.tilesX + 3) / 4;
+            const int lexp = tune_int("NVDR_TUNE_TEX_LIGHT_EXP", 0);
+            const dim3 gridW((unsigned)((((long long)gx4 * p.tilesY * p.n + 7) / 8) * 8));
+#define NVDR_TEX_LIGHT_W(FILTER)                                                                                    \
+    do {                                                                                                            \
+        if (C == 1)      hipLaunchKernelGGL((k_tex_grad_light_w<FILTER, 1>), gridW, dim3(256), 0, stream, p, gx4, lexp);   \
+        else if (C == 2) hipLaunchKernelGGL((k_tex_grad_light_w<FILTER, 2>), gridW, dim3(256), 0, stream, p, gx4, lexp);   \
+        else if (C == 3) hipLaunchKernelGGL((k_tex_grad_light_w<FILTER, 3>), gridW, dim3(256), 0, stream, p, gx4, lexp);   \
+        else             hipLaunchKernelGGL((k_tex_grad_light_w<FILTER, 4>), gridW, dim3(256), 0, stream, p, gx4, lexp);   \
+    } while (0)
+            if (C >= 1 && C <= 4 && (long long)N * H * W * 16 < (1ll << 32) && tune_int("NVDR_TUNE_TEX_LIGHT_W", 1)) {     // one wave per block (k_tex_grad_light_w; 32-bit byte offsets)
+                if (filter_mode == TEX_LINEAR) NVDR_TEX_LIGHT_W(TEX_LINEAR);
+                else if (filter_mode == TEX_LMN) NVDR_TEX_LIGHT_W(TEX_LMN);
+                else NVDR_TEX_LIGHT_W(TEX_LML);
+            }
+            else if (filter_mode == TEX_LINEAR) NVDR_TEX_LIGHT(TEX_LINEAR);
             else if (filter_mode == TEX_LMN) NVDR_TEX_LIGHT(TEX_LMN);
             else NVDR_TEX_LIGHT(TEX_LML);
             NVDR_LAUNCH_CHECK();
