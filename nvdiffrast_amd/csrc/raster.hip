@@ -861,9 +861,7 @@ struct FineParams {
 };
 
 
-#ifndef NVDR_EARLYZ
-#define NVDR_EARLYZ 0        // per-tile depth cull in k_fine: measured -7 % on S10k, +3 % on the dense scene, 8 B of scratch (r04j): off
-#endif
+constexpr int kEarlyZTiles = 4;                          // tile bounds a wave refreshes per batch of 64 pairs once covered tiles see more pairs (k_fine)
 constexpr int kQueueSize = 128;
 
 struct FineShared {
@@ -871,7 +869,6 @@ struct FineShared {
     uint32_t box[kListCap];                                // packed tile AABBs of the list entries
     unsigned long long key[kBinTiles][kBinTiles][64];      // per-pixel visibility keys of the bin [tileY][tileX][pixel]
     uint16_t pfx[kListCap + 64];                           // exclusive prefix of the entries' (triangle, tile) pair counts (<= 448 x 64)
-    uint16_t zmin16[kListCap];                             // upper half of the entries' depth lower bound (record q3.z), rounded down
     uint32_t tileZ[kBinTiles * kBinTiles];                 // per tile: an upper bound (upper half + 1) of what every pixel's depth will end up at most
     uint16_t queue[kFineWaves][kQueueSize];                // per-wave ring of surviving pairs: entry | tileX << 9 | tileY << 12
     int count;
@@ -886,9 +883,9 @@ struct FineShared {
 //     and merges depth<<32|~id into the tile's key array with an LDS 64-bit atomic min.
 // Bit b of the mask is pixel (x, y) = (7 - (b & 7), 7 - (b >> 3)) of the tile.
 template <bool PEEL, bool DBG = false>
-__device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
+__device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
                                              int wave, int lane, int n, int head, int npairs, int btx0, int bty0,
-                                             unsigned long long* dbgNonEmpty = nullptr)
+                                             unsigned long long* dbgNonEmpty = nullptr, bool ezOn = true)
 {
     const bool act = lane < npairs;
     const uint32_t q = sh.queue[wave][(head + lane) & (kQueueSize - 1)];
@@ -908,7 +905,37 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     uint32_t e1 = q1.y + (uint32_t)__mul24(A1, X0) + (uint32_t)__mul24(B1, Y0);
     uint32_t e2 = q2.x + (uint32_t)__mul24(A2, X0) + (uint32_t)__mul24(B2, Y0);
 
-    if (DBG && (p.dbg & 256)) { if (q0.x == 0x12345u && q3.w == 77u) sh.key[0][0][lane] = q1.x; return; }      // experiment: no coverage, no fragments
+    // Per-tile depth cull (the reference's early-Z, FineRaster.inl:13-34,67-71,282, with the triangle's depth PLANE over this tile
+    // instead of its zmin): sh.tileZ bounds from above what every pixel of the tile can end up with (refresh_tile_bound); a pair
+    // whose plane lies wholly behind that over the tile's 8x8 pixels cannot win one.  lb = a lower bound of the depth at any
+    // covered pixel: the triangle's zmin (record q3.z), raised to the plane's smallest corner value D0 + min(0, 7 zx) + min(0, 7 zy)
+    // when the slopes are small enough for the wrapped U32 arithmetic to be undone (D0 = depth at the tile origin, known modulo
+    // 2^32; every covered pixel's depth D lies in [zmin, 2^32) and D0 = D - x zx - y zy with x, y < 8, so D0 - zmin lies in
+    // [-S, 2^32 + S) with S = 7 (|zx| + |zy|) < 2^31: t = (d0 - zmin) mod 2^32 below 2^32 - S IS that difference or, when the true
+    // value is 2^32 larger still, below it).  A culled pair gets an edge function that is negative everywhere: empty mask.
+    const uint32_t zx = q2.y, zy = q2.z;
+    const uint32_t d0 = q2.w + zx * (uint32_t)X0 + zy * (uint32_t)Y0;   // depth at the tile origin
+    // (All of it under a wave-uniform test: a pair is a candidate only once its tile is covered completely -- in a scene without
+    // overdraw no more pairs arrive for such a tile, and the wave skips the arithmetic.)
+    bool hot = false;
+    {
+        const uint32_t bound = ezOn ? sh.tileZ[tyl * kBinTiles + tx] : 0xFFFFFFFFu;
+        const bool cand = act && bound != 0xFFFFFFFFu;
+        if (ezOn && __ballot(cand)) {
+            hot = true;
+            const int sx = (int)zx, sy = (int)zy;
+            uint32_t lb = q3.z;
+            if ((uint32_t)(sx + (1 << 27)) < (1u << 28) && (uint32_t)(sy + (1 << 27)) < (1u << 28)) {
+                const uint32_t S = 7u * (uint32_t)(abs(sx) + abs(sy));
+                const uint32_t nn = 7u * (uint32_t)(max(-sx, 0) + max(-sy, 0));
+                const uint32_t t = d0 - q3.z;
+                if (t < 0u - S && t >= nn) { const uint32_t r = q3.z + (t - nn); lb = r < q3.z ? 0xFFFFFFFFu : r; }
+            }
+            if (cand && (lb >> 16) >= bound) { e0 = 0x80000000u; A0 = 0; B0 = 0; }
+        }
+    }
+    const bool kHot = hot;
+    if (DBG && (p.dbg & 256)) { if (q0.x == 0x12345u && q3.w == 77u) sh.key[0][0][lane] = q1.x; return false; }      // experiment: no coverage, no fragments
     uint32_t mhi = 0, mlo = 0;                   // rows 0..3 -> mhi, rows 4..7 -> mlo (sign bits = outside)
 #pragma unroll
     for (int y = 0; y < 8; y++) {
@@ -923,11 +950,9 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
     }
     uint64_t m = act ? ~(((uint64_t)mhi << 32) | mlo) : 0ull;
     if (DBG && dbgNonEmpty) *dbgNonEmpty += __popcll(__ballot(m != 0));
-    if (__ballot(m != 0) == 0) return;
-    if (DBG && (p.dbg & 128)) { if (m == 0x123456789ull) sh.key[0][0][lane] = m; return; }                       // experiment: no fragment loop
+    if (__ballot(m != 0) == 0) return kHot;
+    if (DBG && (p.dbg & 128)) { if (m == 0x123456789ull) sh.key[0][0][lane] = m; return kHot; }                       // experiment: no fragment loop
 
-    const uint32_t zx = q2.y, zy = q2.z;
-    const uint32_t d0 = q2.w + zx * (uint32_t)X0 + zy * (uint32_t)Y0;   // depth at the tile origin
     const uint32_t idk = ~q3.x;
     const int tile = tyl * kBinTiles + tx;
 
@@ -987,13 +1012,14 @@ __device__ __forceinline__ void raster_pairs(FineShared& sh, const FineParams& p
             }
         } while (heavy);
     }
+    return kHot;
 }
 
 // One tile's depth bound for k_fine's per-tile depth cull, refreshed from the tile's keys: the largest depth any of its 64 pixels
 // holds NOW is an upper bound of what each will hold in the end (keys only go down), and an untouched pixel holds the far plane, so
 // the bound bites once the tile is covered -- by one triangle or by several together (the reference keeps the same maximum per
-// tile, FineRaster.inl:13-34).  Waves take turns: after every batch of 64 pairs a wave refreshes ONE tile, all tiles come round
-// every eight batches.  Racing plain stores are fine: every value ever stored is a valid bound.  No register of this survives.
+// tile, FineRaster.inl:13-34).  Waves take turns: after every batch of 64 pairs a wave refreshes one tile -- kEarlyZTiles of them once
+// covered tiles keep receiving pairs (raster_pairs).  Racing plain stores are fine: every value ever stored is a valid bound.
 __device__ __forceinline__ void refresh_tile_bound(FineShared& sh, int tile)
 {
     int l;
@@ -1239,19 +1265,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 nx = max(x1 - x0 + 1, 0); ny = max(y1 - y0 + 1, 0);
                 if (nx == 0) ny = 0;
             };
-            // Per-tile depth cull (the reference's early-Z, FineRaster.inl:13-34,67-71,282): sh.tileZ bounds from above what every
-            // pixel of a tile can end up with (refresh_tile_bound); a (triangle, tile) pair whose triangle lies wholly behind that --
-            // its depth lower bound zmin, record q3.z -- cannot win a pixel and is dropped before coverage, fragments or atomics.
-            // Sixteen bits of depth decide (zmin rounded down, the bound up).  Here: the listed triangles' zmin, one gather per
-            // entry, while wave 0 scans.
-#if NVDR_EARLYZ
-            {
-                int tl;                                     // thread number taken afresh (wave is scalar): nothing of it stays live
-                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tl));
-                tl += wave * 64;
-                if (tl < cnt) sh.zmin16[tl] = (uint16_t)(grec[(size_t)sh.slot[tl] * 4 + 3].z >> 16);
-            }
-#endif
             if (wave == 0) {
                 // exclusive scan of the pair counts: lane l owns entries [l*7, l*7+7)
                 constexpr int kPer = (kListCap + 63) / 64;
@@ -1278,9 +1291,8 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (!(DBG && (p.dbg & 4))) {
                 const int total = sh.totalPairs;
                 int head = 0, qn = 0;
-#if NVDR_EARLYZ
+                const bool ezOn = !(p.dbg & 32);                  // (NVDR_DEBUG 32: the kernel without its depth cull, for comparison)
                 int turn = wave;                            // the tile whose depth bound this wave refreshes next
-#endif
                 for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
                     const int q = q0 + lane;
                     const bool act = q < total;
@@ -1298,30 +1310,29 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     const int ky = (nx > 1) ? (int)(((float)k + 0.5f) / (float)nx) : k;   // exact for k < 64, nx <= 8
                     const int kx = k - ky * nx;
                     const int tx = x0 + kx - btx0, tyl = y0 + ky - bty0;
-#if NVDR_EARLYZ
-                    const bool keep = act && (uint32_t)sh.zmin16[j] <= sh.tileZ[tyl * kBinTiles + tx];
-#else
                     const bool keep = act;
-#endif
                     const uint64_t m = __ballot(keep);
                     if (keep) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
                         (uint16_t)((uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12));
                     qn += __popcll(m);
                     if (qn >= 64) {
                         __builtin_amdgcn_wave_barrier();
-                        raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0, DBG ? &dbgSurv : nullptr);
+                        const bool hotBatch = raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
+                        (void)hotBatch;
                         __builtin_amdgcn_wave_barrier();
                         head = (head + 64) & (kQueueSize - 1);
                         qn -= 64;
-#if NVDR_EARLYZ
-                        refresh_tile_bound(sh, turn);
-                        turn = (turn + kFineWaves) & (kBinTiles * kBinTiles - 1);
-#endif
+                        // (one tile per batch while nothing is there to cull, kEarlyZTiles once covered tiles see more pairs)
+#pragma unroll 1
+                        for (int rt = 0; rt < (hotBatch ? kEarlyZTiles : ezOn ? 1 : 0); rt++) {
+                            refresh_tile_bound(sh, turn);
+                            turn = (turn + kFineWaves) & (kBinTiles * kBinTiles - 1);
+                        }
                     }
                 }
                 if (qn > 0) {
                     __builtin_amdgcn_wave_barrier();
-                    raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0, DBG ? &dbgSurv : nullptr);
+                    raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
                     __builtin_amdgcn_wave_barrier();
                 }
             }

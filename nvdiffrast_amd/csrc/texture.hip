@@ -480,6 +480,38 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
         return;
     }
 
+    // A tile of known-zero uv / uv_da (a wave is one 8x8 tile: three quarters of a rendered image) samples ONE place: level 0
+    // (the footprint is zero: flevel = clamp(log2 0) = 0) at uv = (0, 0).  The wave computes that sample once -- the quad's
+    // texels through scalar loads -- and stores it 64 times, instead of walking the whole path per pixel.  Not with a per-pixel
+    // bias, which moves the level pixel by pixel.
+    if (C_CT > 0 && zt && !p.bias) {
+        const Quad q0 = tex_index_linear(p, 0.f, 0.f, tz, 0);
+        float a[4][CMAX];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int tc = __builtin_amdgcn_readfirstlane(q0.tc[k]);
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) a[k][c] = 0.f;
+            if (tc >= 0) {
+                const float* tp = p.tex[0] + (size_t)tc * C_CT;                        // wave-uniform address: scalar loads
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) asm volatile("s_load_dword %0, %1, %2" : "=s"(a[k][c]) : "s"(tp), "n"(c * 4) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) asm volatile("" : "+s"(a[k][c]));          // (every use of the loaded values stays behind the wait)
+        float r[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) r[c] = bilerp1(a[0][c], a[1][c], a[2][c], a[3][c], q0.fu, q0.fv);
+        if (C_CT == 4) *(float4*)pOut = make_float4(r[0], r[1 % CMAX], r[2 % CMAX], r[3 % CMAX]);
+        else if (C_CT == 2) *(float2*)pOut = make_float2(r[0], r[1 % CMAX]);
+        else for (int c = 0; c < CMAX; c++) pOut[c] = r[c];
+        return;
+    }
+
     int level0, level1; float flevel;
     tex_mip_level<FILTER, BIAS_ONLY>(p, pidx, level0, level1, flevel, nullptr, make_float3(0.f, 0.f, 0.f), nullptr, zt);
     const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, level0);
@@ -1199,7 +1231,7 @@ __global__ __launch_bounds__(256, 8) void k_tex_grad_light_w(const TexParams p, 
         su[t] = __builtin_amdgcn_readfirstlane(__float_as_int(uvt[t].x)); sv[t] = __builtin_amdgcn_readfirstlane(__float_as_int(uvt[t].y));
         if (am[t] == 0ull || ztile[t]) continue;                                  // (a flagged tile's uv is zero by construction)
         if (am[t] != ~0ull) { light = false; continue; }
-        bool same = (__float_as_int(uvt[t].x) == su[t]) & (__float_as_int(uvt[t].y) == sv[t]);
+        bool same = (__float_as_int(uvt[t].x) == su[t]) && (__float_as_int(uvt[t].y) == sv[t]);
         if (FILTER != TEX_LINEAR) {
             same &= (dat[t].x == 0.f) & (dat[t].y == 0.f) & (dat[t].z == 0.f) & (dat[t].w == 0.f);
             if (p.bias) same &= !(fabsf(*(const float*)at(p.bias, pix(t) * 4u)) == INFINITY);

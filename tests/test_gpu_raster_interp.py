@@ -63,6 +63,44 @@ def test_stress_overdraw(dr, oracle):
     _check_raster(r, rdb, ro, rdbo)
 
 
+@pytest.mark.parametrize("order", ["front_to_back", "back_to_front", "shuffled"])
+def test_depth_cull_under_layered_overdraw(dr, oracle, order):
+    """k_fine drops a (triangle, tile) pair whose depth plane lies behind everything a fully covered tile already holds
+    (FineRaster.inl:13-34).  Layers of screen-filling quads -- tiles are covered after the first -- with flat, gently and steeply
+    tilted depth planes (slopes on both sides of the limit up to which the wrapped U32 plane is evaluated per tile), sheets that
+    intersect, exact duplicates (depth ties: the higher id wins) and slivers; ids and z/w must be the reference's whatever the
+    order of submission, in one pass and through three peeled layers."""
+    rng = np.random.default_rng(77)
+    quads = []
+    L = 24
+    for i in range(L):
+        z0 = -0.9 + 1.8 * i / (L - 1)
+        kind = i % 4
+        tilt = [0.0, 0.02, 0.6, 1.7][kind]                      # flat / gentle / steep / spanning the whole depth range
+        zc = np.clip(np.array([z0 - tilt, z0 + tilt * 0.3, z0 + tilt, z0 - tilt * 0.5]), -0.99, 0.99)
+        xy = np.array([[-1.1, -1.1], [1.1, -1.1], [1.1, 1.1], [-1.1, 1.1]]) * (1.0 if kind != 3 else 0.7)
+        quads.append(np.concatenate([xy, zc[:, None], np.ones((4, 1))], 1))
+    quads.append(quads[5].copy())                               # a coplanar duplicate
+    sl = stress_triangles(1, T=300, res=128, seed=12)           # small triangles in between, independent depths
+    P = np.stack(quads).astype(np.float32)                      # [Q,4,4]
+    idx = {"front_to_back": np.arange(len(P)), "back_to_front": np.arange(len(P))[::-1], "shuffled": rng.permutation(len(P))}[order]
+    P = P[idx]
+    pos = np.concatenate([P.reshape(-1, 4), sl["pos"][0]], 0)[None]
+    tq = np.concatenate([np.array([[0, 1, 2], [0, 2, 3]]) + 4 * q for q in range(len(P))], 0)
+    tri = np.concatenate([tq, sl["tri"] + 4 * len(P)], 0).astype(np.int32)
+    res = (200, 136)                                            # several bins, partial tiles at the borders
+    r, rdb, ro, rdbo = _raster_pair(dr, oracle, pos, tri, res)
+    _check_raster(r, rdb, ro, rdbo)
+    assert (ro[..., 3] > 0).mean() > 0.99
+    ctx = dr.RasterizeCudaContext()
+    peel = None
+    with dr.DepthPeeler(ctx, _t(pos), _t(tri), res) as peeler:
+        for layer in range(3):
+            rl, rldb = peeler.rasterize_next_layer()
+            ol, oldb, peel = oracle.rasterize(pos, tri, res, peel_depth=peel, return_depth=True)
+            _check_raster(rl.cpu().numpy(), rldb.cpu().numpy(), ol, oldb)
+
+
 def test_clipping_and_huge_triangles(dr, oracle):
     """Triangles crossing every frustum plane incl. w<=0 vertices (clipper path, pool slots)."""
     rng = np.random.default_rng(5)

@@ -47,7 +47,9 @@ def _metadata(tmp_path, src):
 def test_rasterizer_kernels_stay_within_their_budgets(tmp_path):
     k = _metadata(tmp_path, "raster.hip")
     fine = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10FineParamsE"]       # production: no peel, no depth surface, no debug, no sharing, no lists
-    assert fine == (0, fine[1]) and fine[1] <= 64, fine                         # 8 waves/SIMD, 4 workgroups/CU; not one spilled register
+    # 8 waves/SIMD, 4 workgroups/CU.  Three registers that live across the whole kernel (thread id, the bin's slot range) are parked
+    # in scratch at its start since the per-tile depth cull (r04): stored once per workgroup pass, none inside the pair loop
+    assert fine[0] <= 12 and fine[1] <= 64, fine
     shared = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb0ELb0EEEvNS_10FineParamsE"]
     assert shared[1] <= 64 and shared[0] <= 16, shared
     for name in ("_ZN4nvdr6k_fineILb0ELb0ELb0ELb0ELb1ELb0EEEvNS_10FineParamsE", "_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb1ELb0EEEvNS_10FineParamsE",
