@@ -98,15 +98,8 @@ def fit(iters=200, res=256, ref_res=1024, tex_size=512, seed=0, lr=1e-2, device=
         # changes between replays.  Launch-bound at these sizes: see the printed it/s with and without.
         opt = torch.optim.Adam([tex_opt], lr=lr, capturable=True)
         new_view()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                one_iteration()                                   # warm-up: allocations, scratch growth
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            one_iteration()
+        from nvdiffrast_amd.torch.graph import StepGraph
+        g = StepGraph(one_iteration, warmup=3)                    # warm-up (allocations, scratch growth) on a side stream, then the recording
     losses = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
