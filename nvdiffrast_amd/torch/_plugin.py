@@ -133,6 +133,7 @@ def _require(cond, func, msg):
 # MI355X).  The public torch.cuda helpers (current_stream(), the `device` context manager) cost ~6 us per use in index
 # normalisation and object construction; these go to the same C entry points directly.
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream(device):
@@ -151,7 +152,7 @@ class _on_device:
         self.prev = -1
 
     def __enter__(self):
-        cur = torch.cuda.current_device()
+        cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
         if cur != self.idx:
             self.prev = cur
             torch.cuda.set_device(self.idx)
@@ -251,30 +252,37 @@ class RasterizeCRStateWrapper:
 def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     """torch_rasterize.cpp:43-166."""
     fn = "rasterize_fwd_cuda"
-    dev = _check_device(fn, pos=pos, tri=tri)
-    _check_cpu(fn, ranges=ranges)
-    _check_contiguous(fn, pos=pos, tri=tri, ranges=ranges)
-    _check_f32(fn, pos=pos)
-    _check_i32(fn, tri=tri, ranges=ranges)
-    _require(pos.get_device() == state.cuda_device_idx, fn,
-             "CudaRaster context must must reside on the same device as input tensors")
-
-    instance_mode = pos.dim() > 2
-    if instance_mode:
-        _require(pos.dim() == 3 and pos.size(0) > 0 and pos.size(1) > 0 and pos.size(2) == 4, fn,
-                 "instance mode - pos must have shape [>0, >0, 4]")
-    else:
-        _require(pos.dim() == 2 and pos.size(0) > 0 and pos.size(1) == 4, fn, "range mode - pos must have shape [>0, 4]")
-        _require(ranges.dim() == 2 and ranges.size(0) > 0 and ranges.size(1) == 2, fn,
-                 "range mode - ranges must have shape [>0, 2]")
-    _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
+    ps, ts = pos.shape, tri.shape
+    dev = pos.device
+    instance_mode = len(ps) > 2
+    # The common case -- everything in order -- is decided by ONE expression (host time is the step time of small batches);
+    # anything else goes through the reference's checks one by one, for the reference's message (torch_rasterize.cpp:47-77).
+    if not (pos.is_cuda and tri.device == dev and dev.index == state.cuda_device_idx and ranges.device.type == "cpu"
+            and pos.dtype is torch.float32 and tri.dtype is torch.int32 and ranges.dtype is torch.int32
+            and pos.is_contiguous() and tri.is_contiguous() and ranges.is_contiguous()
+            and len(ps) == 3 and ps[0] > 0 and ps[1] > 0 and ps[2] == 4 and len(ts) == 2 and ts[0] > 0 and ts[1] == 3):
+        dev = _check_device(fn, pos=pos, tri=tri)
+        _check_cpu(fn, ranges=ranges)
+        _check_contiguous(fn, pos=pos, tri=tri, ranges=ranges)
+        _check_f32(fn, pos=pos)
+        _check_i32(fn, tri=tri, ranges=ranges)
+        _require(pos.get_device() == state.cuda_device_idx, fn,
+                 "CudaRaster context must must reside on the same device as input tensors")
+        if instance_mode:
+            _require(pos.dim() == 3 and pos.size(0) > 0 and pos.size(1) > 0 and pos.size(2) == 4, fn,
+                     "instance mode - pos must have shape [>0, >0, 4]")
+        else:
+            _require(pos.dim() == 2 and pos.size(0) > 0 and pos.size(1) == 4, fn, "range mode - pos must have shape [>0, 4]")
+            _require(ranges.dim() == 2 and ranges.size(0) > 0 and ranges.size(1) == 2, fn,
+                     "range mode - ranges must have shape [>0, 2]")
+        _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
 
     height, width = int(resolution[0]), int(resolution[1])
-    depth = pos.size(0) if instance_mode else ranges.size(0)
+    depth = ps[0] if instance_mode else ranges.size(0)
     _require(height > 0 and width > 0, fn, "resolution must be [>0, >0]")
 
-    V = pos.size(1) if instance_mode else pos.size(0)
-    T = tri.size(0)
+    V = ps[1] if instance_mode else ps[0]
+    T = ts[0]
     if instance_mode:
         max_tri, ranges_dev = T, None
     else:
@@ -520,15 +528,22 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec,
     fn = "interpolate_fwd_da"
     enable_da = (rast_db is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
     instance_mode = attr.dim() > 2
-    if enable_da:
+    dev = attr.device
+    f32 = torch.float32
+    if (attr.is_cuda and rast.device == dev and tri.device == dev and attr.dtype is f32 and rast.dtype is f32 and tri.dtype is torch.int32
+            and attr.is_contiguous() and rast.is_contiguous() and tri.is_contiguous()
+            and (not enable_da or (rast_db.device == dev and rast_db.dtype is f32 and rast_db.is_contiguous()))):
+        pass                                   # (the common case in one expression; otherwise the reference's checks and messages)
+    elif enable_da:
         dev = _check_device(fn, attr=attr, rast=rast, tri=tri, rast_db=rast_db)
         _check_contiguous(fn, attr=attr, rast=rast, tri=tri, rast_db=rast_db)
         _check_f32(fn, attr=attr, rast=rast, rast_db=rast_db)
+        _check_i32(fn, tri=tri)
     else:
         dev = _check_device(fn, attr=attr, rast=rast, tri=tri)
         _check_contiguous(fn, attr=attr, rast=rast, tri=tri)
         _check_f32(fn, attr=attr, rast=rast)
-    _check_i32(fn, tri=tri)
+        _check_i32(fn, tri=tri)
 
     _require(rast.dim() == 4 and rast.size(0) > 0 and rast.size(1) > 0 and rast.size(2) > 0 and rast.size(3) == 4, fn,
              "rast must have shape[>0, >0, >0, 4]")
@@ -656,15 +671,24 @@ def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_
     attr and pos must index the same vertices with the same `tri`."""
     fn = "interpolate_rasterize_grad"
     enable_da = (rast_db is not None) and (dda is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
-    if enable_da:
+    dev = attr.device
+    f32 = torch.float32
+    if (attr.is_cuda and rast.device == dev and tri.device == dev and pos.device == dev and dy.device == dev
+            and attr.dtype is f32 and rast.dtype is f32 and pos.dtype is f32 and dy.dtype is f32 and tri.dtype is torch.int32
+            and attr.is_contiguous() and rast.is_contiguous() and tri.is_contiguous() and pos.is_contiguous()
+            and (not enable_da or (rast_db.device == dev and dda.device == dev and rast_db.dtype is f32 and dda.dtype is f32
+                                   and rast_db.is_contiguous()))):
+        pass                                   # (the common case in one expression; otherwise check by check, for the messages)
+    elif enable_da:
         dev = _check_device(fn, attr=attr, rast=rast, tri=tri, pos=pos, dy=dy, rast_db=rast_db, dda=dda)
         _check_contiguous(fn, attr=attr, rast=rast, tri=tri, pos=pos, rast_db=rast_db)
         _check_f32(fn, attr=attr, rast=rast, pos=pos, dy=dy, rast_db=rast_db, dda=dda)
+        _check_i32(fn, tri=tri)
     else:
         dev = _check_device(fn, attr=attr, rast=rast, tri=tri, pos=pos, dy=dy)
         _check_contiguous(fn, attr=attr, rast=rast, tri=tri, pos=pos)
         _check_f32(fn, attr=attr, rast=rast, pos=pos, dy=dy)
-    _check_i32(fn, tri=tri)
+        _check_i32(fn, tri=tri)
     attr_instance = attr.dim() > 2
     pos_instance = pos.dim() > 2
     _require(rast.dim() == 4 and rast.size(0) > 0 and rast.size(1) > 0 and rast.size(2) > 0 and rast.size(3) == 4, fn,
@@ -694,7 +718,10 @@ def interpolate_rasterize_grad(attr, rast, tri, pos, dy, with_g_rast=True, tile_
     dda_ = dda.contiguous() if enable_da else None
     lst, nlst = _diff_list([] if (diff_attrs_all or not enable_da) else diff_attrs_vec)
     with _on_device(dev):
-        # both zero-initialised gradients from ONE buffer: one fill launch instead of two (small batches are launch-bound)
+        # both zero-initialised gradients from ONE buffer: one fill launch instead of two (small batches are launch-bound).
+        # Consequence: when autograd adopts them, attr.grad and pos.grad are views into one allocation -- pos.grad has
+        # a non-zero storage_offset and each keeps the other's memory alive, unlike the separate tensors of the two-kernel path.
+        # Optimizers and in-place gradient arithmetic do not notice; code that works on .grad's untyped_storage() would.
         tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
         na = (attr.numel() + 3) & ~3                       # keeps g_pos 16-byte aligned
         zeros = torch.zeros((na + pos.numel(),), dtype=torch.float32, device=dev)
