@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void k_interp_fwd(const InterpParams p)
     // the order's bins -- covered bins first, then the ones that are only zeros to store -- instead of a run of the image.
     int pz, obx = 0, oby = 0;
     if (p.ordered) {
+        // (the partner clearing of k_interp_fwd_cols was tried here as well: 0.225 vs 0.227 ms at config 3 -- this variant is bound by
+        // its 805 MB of stores either way)
         if (!decode_block_ordered(p.flags, (p.width + 63) >> 6, (p.height + 4 * kPixels - 1) / (4 * kPixels), 64, 4 * kPixels, obx, oby, pz)) return;
     } else {
         pz = (int)(blockIdx.y + blockIdx.z * 32768u);
@@ -159,8 +161,43 @@ __global__ __launch_bounds__(256) void k_interp_fwd_cols(const InterpParams p, i
     static_assert(K == 1 || K == 2 || K == 4 || K == 8, "K rows of one tile row");
     typedef typename std::conditional<A_CT == 4, float4, float2>::type Row;
     int bx, by, pz;
-    if (p.ordered ? !decode_block_ordered(p.flags, gx, gy, 64, 4 * K, bx, by, pz) : !decode_block(gx, gy, p.depth, bx, by, pz)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (p.ordered) {
+        // Along the work order a covered bin's workgroup also stores the zeros of one EMPTY bin of its XCD's share (the same block
+        // of it), and that bin's own workgroup leaves at once: the launch used to be a latency-bound phase over the covered bins
+        // followed by a store-bound one over the empty bins (35 + 30 us at the headline batch); interleaved, the stores go out
+        // while the other waves of a CU wait for their loads.
+        constexpr int per = 16 / K;                                  // workgroups per bin (64 x 4K pixels each)
+        const TileFlags& t = p.flags;
+        const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        const int slot = j / per, sub = j - slot * per;
+        int own, partner; bool skip;
+        ordered_list_pair(t.nBins, t.order[t.nBins], xcd, slot, own, partner, skip);
+        if (own < 0 || skip) return;
+        auto place = [&](int idx, int& bx_, int& by_, int& pz_) {
+            const int bin = __builtin_amdgcn_readfirstlane(t.order[idx]);
+            pz_ = bin / (t.binsX * t.binsY);
+            const int rem = bin - pz_ * (t.binsX * t.binsY);
+            const int binY = rem / t.binsX;
+            bx_ = rem - binY * t.binsX; by_ = binY * per + sub;
+        };
+        if (partner >= 0) {
+            int qx, qy, qz;
+            place(partner, qx, qy, qz);
+            const int xq = qx * 64 + lane, yq = qy * (4 * K) + wave * K;
+            if (xq < p.width) {
+                Row* o = (Row*)p.out + ((size_t)qz * p.height + yq) * p.width + xq;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (yq + k >= p.height) break;
+                    if constexpr (A_CT == 4) { if (p.streamOut) store_streaming(o + (size_t)k * p.width, make_float4(0.f, 0.f, 0.f, 0.f)); else o[(size_t)k * p.width] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                    else o[(size_t)k * p.width] = make_float2(0.f, 0.f);
+                }
+            }
+        }
+        place(own, bx, by, pz);
+        if (bx >= gx || by >= gy) return;
+    } else if (!decode_block(gx, gy, p.depth, bx, by, pz)) return;
     const int x = bx * 64 + lane, y0 = by * (4 * K) + wave * K;
     if (x >= p.width || y0 >= p.height) return;
     const bool empty = p.flags.empty(pz, y0, x);
@@ -495,7 +532,8 @@ extern "C" int nvdr_interpolate_fwd(const float* attr, const float* rast, const 
             // vector rows: K pixels per thread, staged (k_interp_fwd_cols), along the work order where there is one.  Headline batch /
             // dense scene, us (r04n): one pixel per thread in image order 92 / 130; K = 1: 113 / 145 (ordered 102 / 141); K = 2: 97 / 121
             // (86 / 122); K = 4: 92 / 115 (83 / 117); K = 8: 91 / 119 (81 / 117).  For comparison, torch's copy of the dense
-            // scene's 537 MB takes 100 us on these boxes (tools/write_bw.py: 5.35 TB/s read + written).
+            // scene's 537 MB takes 100 us on these boxes (tools/write_bw.py: 5.35 TB/s read + written).  With the empty bins' zeros
+            // stored by the covered bins' workgroups (ordered launches, see the kernel): 82 -> 75.5 us at the headline batch (r04t).
             const int K = tune_int("NVDR_TUNE_IPFWD_K", 4);
             p.ordered = (p.flags.order && tune_int("NVDR_TUNE_IPFWD_ORDERED", 1)) ? 1 : 0;
             const int gx = (W + 63) / 64, gy = (H + 4 * K - 1) / (4 * K);

@@ -152,6 +152,21 @@ __host__ __device__ inline int ordered_list_index(int nBins, int nCov, int xcd, 
     return -1;
 }
 
+// A covered bin's workgroups may take on the zeros of an empty bin of the same XCD share (k_interp_fwd_cols: the stores of a
+// bin that only needs zeros go out while other waves of the CU wait for their loads, instead of all together at the end of the
+// launch).  For slot `slot` of XCD `xcd`: own = the list index of its own bin (-1: none); partner = the list index of the EMPTY
+// bin this workgroup also clears (-1: none); skip = this is an empty bin that a covered bin's workgroup clears (leave at once).
+__host__ __device__ inline void ordered_list_pair(int nBins, int nCov, int xcd, int slot, int& own, int& partner, bool& skip)
+{
+    const int nEmp = nBins - nCov;
+    const int cc = (nCov + 7) >> 3, ec = (nEmp + 7) >> 3;
+    const int c0 = xcd * cc < nCov ? xcd * cc : nCov, cn = (c0 + cc < nCov ? c0 + cc : nCov) - c0;
+    const int e0 = xcd * ec < nEmp ? xcd * ec : nEmp, en = (e0 + ec < nEmp ? e0 + ec : nEmp) - e0;
+    own = -1; partner = -1; skip = false;
+    if (slot < cn) { own = c0 + slot; if (slot < en) partner = nCov + e0 + slot; }
+    else if (slot - cn < en) { own = nCov + e0 + (slot - cn); skip = (slot - cn) < cn; }
+}
+
 // Ordered counterpart of decode_block() for workgroups of bw x bh pixels (both dividing 64): false = nothing to do.
 __device__ __forceinline__ bool decode_block_ordered(const TileFlags& t, int gx, int gy, int bw, int bh, int& bx, int& by, int& pz)
 {

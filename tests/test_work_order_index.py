@@ -39,6 +39,19 @@ int main()
                 }
             }
             for (int b = 0; b < nBins; b++) if (seen[b] != 1) { printf("entry %d visited %d times (nBins %d nCov %d)\n", b, seen[b], nBins, nCov); return 1; }
+            // the paired form (k_interp_fwd_cols): every entry is handled exactly once -- by its own workgroup, or, an empty bin, by
+            // the covered bin's workgroup that takes it on (whose own workgroup then leaves); partners are always empty bins
+            std::vector<int> handled(nBins, 0);
+            for (int xcd = 0; xcd < 8; xcd++)
+                for (int slot = 0; slot < grid / 8; slot++) {
+                    int own, partner; bool skip;
+                    ordered_list_pair(nBins, nCov, xcd, slot, own, partner, skip);
+                    if (own != ordered_list_index(nBins, nCov, xcd, slot)) { printf("pair: own differs from the plain index\n"); return 1; }
+                    if (own >= 0 && !skip) handled[own]++;
+                    if (skip && (own < nCov || partner >= 0)) { printf("pair: a covered bin is skipped\n"); return 1; }
+                    if (partner >= 0) { if (partner < nCov || partner >= nBins || own < 0 || own >= nCov) { printf("pair: bad partner\n"); return 1; } handled[partner]++; }
+                }
+            for (int b = 0; b < nBins; b++) if (handled[b] != 1) { printf("pair: entry %d handled %d times (nBins %d nCov %d)\n", b, handled[b], nBins, nCov); return 1; }
             for (int e = 0; e < 2; e++) {
                 int lo = 1 << 30, hi = 0, n = e ? nBins - nCov : nCov;
                 for (int x = 0; x < 8; x++) { lo = share[x][e] < lo ? share[x][e] : lo; hi = share[x][e] > hi ? share[x][e] : hi; }
