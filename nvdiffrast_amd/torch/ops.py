@@ -125,7 +125,9 @@ class _LazyGrad(torch.Tensor):
         key = (like.device, like.dtype)
         zero = _LazyGrad._zeros.get(key)
         if zero is None:
-            zero = _LazyGrad._zeros[key] = torch.zeros((), dtype=like.dtype, device=like.device)
+            zero = torch.zeros((), dtype=like.dtype, device=like.device)
+            if not _plugin._is_capturing(like.device):           # (memory allocated while a hipGraph is recorded belongs to the graph's pool)
+                _LazyGrad._zeros[key] = zero
         r = torch.Tensor._make_subclass(cls, zero.expand(like.shape), False)
         r._source, r._index = source, index
         return r
