@@ -457,9 +457,74 @@ template <int FILTER, bool BIAS_ONLY, int C_CT>
 __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
 {
     int px, py, pz; bool inside;
-    if (!tex_pixel(p, px, py, pz, inside) || !inside) return;
     constexpr int CMAX = C_CT > 0 ? C_CT : 1;
     const int C = C_CT > 0 ? C_CT : p.channels;
+    // The sample of a tile of known-zero uv / uv_da (a wave is one 8x8 tile: three quarters of a rendered image): level 0 (the
+    // footprint is zero: flevel = clamp(log2 0) = 0) at uv = (0, 0), ONE place -- computed once per wave, the quad's texels through
+    // scalar loads, and stored 64 times, instead of walking the whole path per pixel.  Not with a per-pixel bias, which moves the
+    // level pixel by pixel.
+    const bool kUniform = C_CT > 0 && FILTER != TEX_NEAREST && !p.bias;
+    float ur[CMAX];
+    bool haveU = false;
+    auto uniform_sample = [&](int tz_) {
+        const Quad q0 = tex_index_linear(p, 0.f, 0.f, tz_, 0);
+        float a[4][CMAX];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int tc = __builtin_amdgcn_readfirstlane(q0.tc[k]);
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) a[k][c] = 0.f;
+            if (tc >= 0) {
+                const float* tp = p.tex[0] + (size_t)tc * CMAX;                        // wave-uniform address: scalar loads
+#pragma unroll
+                for (int c = 0; c < CMAX; c++) asm volatile("s_load_dword %0, %1, %2" : "=s"(a[k][c]) : "s"(tp), "n"(c * 4) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < CMAX; c++) asm volatile("" : "+s"(a[k][c]));          // (every use of the loaded values stays behind the wait)
+#pragma unroll
+        for (int c = 0; c < CMAX; c++) ur[c] = bilerp1(a[0][c], a[1][c], a[2][c], a[3][c], q0.fu, q0.fv);
+        haveU = true;
+    };
+    auto store_texel = [&](float* o, const float* r) {
+        if (C_CT == 4) *(float4*)o = make_float4(r[0], r[1 % CMAX], r[2 % CMAX], r[3 % CMAX]);
+        else if (C_CT == 2) *(float2*)o = make_float2(r[0], r[1 % CMAX]);
+        else for (int c = 0; c < CMAX; c++) o[c] = r[c];
+    };
+    if (kUniform && p.zflags.order) {
+        // Along the work order a covered bin's workgroup also stores the samples of one EMPTY bin of its XCD's share (the same
+        // 16x16 block of it), whose own workgroup leaves at once: the stores of the bins that only need that one sample go out while
+        // the waves with real footprints wait for their gathers (nvdr_device.hpp ordered_list_pair, as in k_interp_fwd_cols).
+        const TileFlags& t = p.zflags;
+        const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        const int slot = j >> 4, sub = j & 15;
+        int own, partner; bool skip;
+        ordered_list_pair(t.nBins, t.order[t.nBins], xcd, slot, own, partner, skip);
+        if (own < 0 || skip) return;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        auto place = [&](int idx, int& x, int& y, int& z) {
+            const int bin = __builtin_amdgcn_readfirstlane(t.order[idx]);
+            z = bin / (t.binsX * t.binsY);
+            const int rem = bin - z * (t.binsX * t.binsY);
+            const int binY = rem / t.binsX, binX = rem - binY * t.binsX;
+            x = (binX * 4 + (sub & 3)) * 16 + (wave & 1) * 8 + (lane & 7);
+            y = (binY * 4 + (sub >> 2)) * 16 + (wave >> 1) * 8 + (lane >> 3);
+        };
+        if (partner >= 0) {
+            int qx, qy, qz;
+            place(partner, qx, qy, qz);
+            const int qtz = (p.texDepth == 1) ? 0 : qz;
+            uniform_sample(qtz);
+            if (qx < p.imgW && qy < p.imgH) store_texel(p.out + ((size_t)qx + (size_t)p.imgW * (qy + (size_t)p.imgH * qz)) * C, ur);
+            if (p.texDepth != 1) haveU = false;                    // (another image may sample another texture slice)
+        }
+        place(own, px, py, pz);
+        inside = px < p.imgW && py < p.imgH;
+        if (!inside) return;
+    } else if (!tex_pixel(p, px, py, pz, inside) || !inside) return;
     const int tz = (p.texDepth == 1) ? 0 : pz;
     const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
     const bool zt = p.zflags.empty(pz, py, px);               // uv = uv_da = 0 known for this tile: not read
@@ -480,35 +545,9 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
         return;
     }
 
-    // A tile of known-zero uv / uv_da (a wave is one 8x8 tile: three quarters of a rendered image) samples ONE place: level 0
-    // (the footprint is zero: flevel = clamp(log2 0) = 0) at uv = (0, 0).  The wave computes that sample once -- the quad's
-    // texels through scalar loads -- and stores it 64 times, instead of walking the whole path per pixel.  Not with a per-pixel
-    // bias, which moves the level pixel by pixel.
-    if (C_CT > 0 && zt && !p.bias) {
-        const Quad q0 = tex_index_linear(p, 0.f, 0.f, tz, 0);
-        float a[4][CMAX];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int tc = __builtin_amdgcn_readfirstlane(q0.tc[k]);
-#pragma unroll
-            for (int c = 0; c < CMAX; c++) a[k][c] = 0.f;
-            if (tc >= 0) {
-                const float* tp = p.tex[0] + (size_t)tc * C_CT;                        // wave-uniform address: scalar loads
-#pragma unroll
-                for (int c = 0; c < CMAX; c++) asm volatile("s_load_dword %0, %1, %2" : "=s"(a[k][c]) : "s"(tp), "n"(c * 4) : "memory");
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int c = 0; c < CMAX; c++) asm volatile("" : "+s"(a[k][c]));          // (every use of the loaded values stays behind the wait)
-        float r[CMAX];
-#pragma unroll
-        for (int c = 0; c < CMAX; c++) r[c] = bilerp1(a[0][c], a[1][c], a[2][c], a[3][c], q0.fu, q0.fv);
-        if (C_CT == 4) *(float4*)pOut = make_float4(r[0], r[1 % CMAX], r[2 % CMAX], r[3 % CMAX]);
-        else if (C_CT == 2) *(float2*)pOut = make_float2(r[0], r[1 % CMAX]);
-        else for (int c = 0; c < CMAX; c++) pOut[c] = r[c];
+    if (kUniform && zt) {
+        if (!haveU) uniform_sample(tz);
+        store_texel(pOut, ur);
         return;
     }
 
