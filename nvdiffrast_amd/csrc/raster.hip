@@ -1291,7 +1291,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (!(DBG && (p.dbg & 4))) {
                 const int total = sh.totalPairs;
                 int head = 0, qn = 0;
-                const bool ezOn = !(p.dbg & 32);                  // (NVDR_DEBUG 32: the kernel without its depth cull, for comparison)
+                // (NVDR_DEBUG 32: the kernel without its depth cull, for comparison.  Not in the list instantiation: a mesh of 32 k+
+                // triangles is a mesh of small triangles -- little fragment work to save -- and the cull's registers cost that
+                // instantiation 8 % at a million triangles, 0.245 -> 0.263 ms)
+                const bool ezOn = !LIST && !(p.dbg & 32);
                 int turn = wave;                            // the tile whose depth bound this wave refreshes next
                 for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
                     const int q = q0 + lane;
