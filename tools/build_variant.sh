@@ -4,7 +4,8 @@
 set -e
 cd "$(dirname "$0")/../nvdiffrast_amd"
 name=$1; src=$2; shift 2
-python -m nvdiffrast_amd._build >/dev/null 2>&1 || (cd .. && python -c "from nvdiffrast_amd import _build; _build.build()")
+# (the other objects are taken from nvdiffrast_amd/build/ as they are: build the main library first, from the sources you mean)
+ls build/*.hip.o >/dev/null
 mkdir -p build/ab_$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function "$@" -c csrc/$src -o build/ab_$name/$src.o
 objs=""
