@@ -736,6 +736,18 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     const float* pDy = p.dy + pidx * C;
     const bool zt = !CUBE && inside && p.zflags.empty(pz, py, px);   // uv = uv_da = 0 known for this tile: not read
 
+    // uv and uv_da (2-D textures) are fetched TOGETHER WITH the upstream gradient, before the block's barrier: their round trip
+    // to memory overlaps dy's and the wait for the block's other waves instead of following both (the kernel is bound by its chain
+    // of dependent loads, section 6: 0.790 -> 0.758 ms at config 3 with the fetch behind dy, same registers).  A pixel whose
+    // upstream gradient turns out to be zero has then fetched them for nothing; where dy is masked to the covered pixels the
+    // background's tiles are flagged and read nothing.
+    constexpr bool kPreUV = !CUBE;
+    float2 preUV = make_float2(0.f, 0.f);
+    float4 preDA = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kPreUV && inside && !zt) {
+        preUV = ((const float2*)p.uv)[pidx];
+        if ((FILTER == TEX_LMN || FILTER == TEX_LML) && !BIAS_ONLY) preDA = ((const float4*)p.uvDA)[pidx];
+    }
     // ---- phase A: all-zero upstream gradients take the early-out (explicit zero stores, :922-971);
     //      the rest publish the block's largest |dy|.
     bool active = false;
@@ -758,16 +770,6 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
                 if (p.gradBias) p.gradBias[pidx] = 0.f;
             }
         }
-    }
-    // uv and uv_da of the active pixels are fetched BEFORE the barrier (2-D textures): their round trip to memory overlaps the
-    // wait for the block's other waves instead of following it (the kernel is bound by its chain of dependent loads, section 6:
-    // 0.790 -> 0.758 ms at config 3, same registers).
-    constexpr bool kPreUV = !CUBE;
-    float2 preUV = make_float2(0.f, 0.f);
-    float4 preDA = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kPreUV && active && !zt) {
-        preUV = ((const float2*)p.uv)[pidx];
-        if ((FILTER == TEX_LMN || FILTER == TEX_LML) && !BIAS_ONLY) preDA = ((const float4*)p.uvDA)[pidx];
     }
     block_max_update(s_max, m);
     __syncthreads();
