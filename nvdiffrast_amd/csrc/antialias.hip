@@ -248,16 +248,51 @@ __device__ __forceinline__ float aa_analyse_item(const AAParams& p, int item_idx
         const float fx = (float)px + .5f - p.xh;
         const float fy = (float)py + .5f - p.yh;
         float x[3], y[3], ox[3], oy[3];
+        // The three corners first, then the three edges' table lookups SIDE BY SIDE -- one probe of each per round, so the
+        // rounds' loads are in flight together -- then the three opposite vertices together: looked up one edge after the other
+        // (probe, corner, opposite vertex, next edge ...) an item was a chain of up to nine dependent loads, and the kernel
+        // waits for memory 83 % of its time.  The probe sequence of each edge is hash_find_vertex's.
+        float4 c[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) c[k] = vb[vi[k]];
+        int op[3];
+        unsigned long long key[3];
+        unsigned hidx[3], hskip[3];
+        bool open[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const int i = (k + 1) % 3, j = (k + 2) % 3;
-            int op = hash_find_vertex(p, vi[j], vi[i], vi[k]);      // vertex opposite to corner k across edge (i, j)
-            if (op >= p.numVertices) op = -1;                       // a table built for another mesh may name vertices this one lacks
-            const float4 c = vb[vi[k]];
-            const float4 o = (op < 0) ? c : vb[op];
-            const float w = 1.f / c.w, ow = 1.f / o.w;
-            x[k] = aa_proj(c.x, w, p.xh, fx);   y[k] = aa_proj(c.y, w, p.yh, fy);
-            ox[k] = aa_proj(o.x, ow, p.xh, fx); oy[k] = aa_proj(o.y, ow, p.yh, fy);
+            const int i = (k + 1) % 3, j = (k + 2) % 3;             // vertex opposite to corner k across edge (i, j)
+            op[k] = -1;
+            open[k] = vi[j] != vi[i];
+            key[k] = edge_key(vi[j], vi[i]);
+            hash_start(key[k], p.hashMask, hidx[k], hskip[k]);
+        }
+        while (open[0] | open[1] | open[2]) {
+            uint4 e[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) e[k] = p.hash[open[k] ? hidx[k] : 0u];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (!open[k]) continue;
+                const unsigned long long kk = (unsigned long long)e[k].x | ((unsigned long long)e[k].y << 32);
+                if (kk == key[k] || kk == 0ull) {
+                    const int a = (int)e[k].z - 1, b = (int)e[k].w - 1;
+                    if (kk != 0ull) op[k] = (a == vi[k]) ? b : (b == vi[k]) ? a : -1;
+                    open[k] = false;
+                } else hidx[k] = (hidx[k] + hskip[k]) & p.hashMask;
+            }
+        }
+        float4 o[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (op[k] >= p.numVertices) op[k] = -1;                 // a table built for another mesh may name vertices this one lacks
+            o[k] = vb[op[k] < 0 ? vi[k] : op[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float w = 1.f / c[k].w, ow = 1.f / o[k].w;
+            x[k] = aa_proj(c[k].x, w, p.xh, fx);   y[k] = aa_proj(c[k].y, w, p.yh, fy);
+            ox[k] = aa_proj(o[k].x, ow, p.xh, fx); oy[k] = aa_proj(o[k].y, ow, p.yh, fy);
         }
 
         // Orientation of the triangle and of each "wing" (edge + opposite vertex): an edge whose wing
