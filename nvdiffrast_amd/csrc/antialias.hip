@@ -400,6 +400,10 @@ __global__ __launch_bounds__(256) void k_aa_grad(const AAParams p)
             if (tri1) { px += 1 - d; py += d; }
             if (tri >= 0 && tri < p.numTriangles) {
                 st.alpha = alpha; st.pix0 = (int)pixel0; st.pix1 = (int)pixel1;      // colour part: emitted transposed below
+                // (the silhouette edge's two vertex indices are fetched BEFORE the colour loop, whose loads they do not depend on:
+                // behind it they were one more link in the item's chain of dependent loads)
+                const int e1 = (di + 1) % 3, e2 = (di + 2) % 3;
+                const int ve[2] = {p.tri[3 * tri + e1], p.tri[3 * tri + e2]};
                 const float* pDy = p.dy + (alpha > 0.f ? pixel0 : pixel1) * C;
                 const float* pColor0 = p.color + pixel0 * C;
                 const float* pColor1 = p.color + pixel1 * C;
@@ -413,8 +417,6 @@ __global__ __launch_bounds__(256) void k_aa_grad(const AAParams p)
                 // pixel pair is horizontal (:338-365).  dL/dc = -dd; the adjoint runs from c back through the
                 // screen-space edge ends to the clip-space vertices (:508-546).  1 / (y2 - y1) is regularised by
                 // a signed 1e-3 pixel; saturated blends (|alpha| >= 1/2) carry no position gradient.
-                const int e1 = (di + 1) % 3, e2 = (di + 2) % 3;
-                const int ve[2] = {p.tri[3 * tri + e1], p.tri[3 * tri + e2]};
                 if (dd != 0.f && !(ve[0] < 0 || ve[0] >= p.numVertices || ve[1] < 0 || ve[1] >= p.numVertices)) {
                     const size_t vbase = p.instance ? (size_t)pz * p.numVertices : 0;
                     // axis a = direction of the pixel pair (0: x, 1: y), b = the other one
