@@ -40,6 +40,12 @@ struct FusedParams {
     TileFlags flags;                                        // which 8x8 tiles of rast show a triangle at all, or f == nullptr
 };
 
+// Largest magnitude as BITS: for non-negative floats unsigned order is float order, inf and NaN patterns sort above every finite
+// one (so a NaN anywhere survives to the block maximum, which is what routes the block to the plain-atomic path), and the whole
+// update is one v_and + one v_max_u32 -- max_abs_keep_nan is a compare, a select, an fmax and an fabs.  This kernel runs at 95 %
+// of its vector issue rate (profiles/r04w_pmc_ch.log): instructions are its time.
+__device__ __forceinline__ uint32_t mag_bits(float v) { return (uint32_t)__float_as_int(v) & 0x7FFFFFFFu; }
+
 constexpr int kFuBlockW = 64;
 constexpr int kFuBlockH = 16;
 constexpr int kFuWaves = 8;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
     float b0[kFuRows], b1[kFuRows];
     float4 yreg[kFuRows];
     float g[kFuRows][9];
-    float mA = 0.f, mP = 0.f;
+    uint32_t uA = 0u, uP = 0u;                            // largest attribute / position contribution of this lane, as magnitude bits
 
     // ---- phase A -----------------------------------------------------------------------
 #pragma unroll
@@ -169,14 +175,14 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
             const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
             gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
             gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
-            ymax = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y), y.z), y.w);
+            ymax = __int_as_float((int)max(max(mag_bits(y.x), mag_bits(y.y)), max(mag_bits(y.z), mag_bits(y.w))));
             yreg[r] = y;
         } else if (A_CT == 2) {
             const float2 y = *(const float2*)pdy;
             const float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
             gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y);
             gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y);
-            ymax = max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y);
+            ymax = __int_as_float((int)max(mag_bits(y.x), mag_bits(y.y)));
             yreg[r] = make_float4(y.x, y.y, 0.f, 0.f);
         } else {
             for (int i = 0; i < A; i++) {
@@ -184,11 +190,11 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
                 const float s2v = a2[i];
                 gb0 += y * (a0[i] - s2v);
                 gb1 += y * (a1[i] - s2v);
-                ymax = max_abs_keep_nan(ymax, y);
+                ymax = __int_as_float((int)max(mag_bits(ymax), mag_bits(y)));
             }
         }
         if (WRITE_GRAST) ((float4*)p.gradRaster)[pidx] = make_float4(gb0, gb1, 0.f, 0.f);
-        mA = max_abs_keep_nan(mA, ymax * bmax);             // >= every |b_k * dy_i| (rounding is monotone)
+        uA = max(uA, mag_bits(ymax * bmax));                // >= every |b_k * dy_i| (rounding is monotone)
 
         float4 gdb = make_float4(0.f, 0.f, 0.f, 0.f);       // gradient of rast_db = (du/dX, du/dY, dv/dX, dv/dY)
         if (ENABLE_DA) {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
                 gdb.z += dsdv * d.x; gdb.w += dsdv * d.y;
                 const float du = d.x * db.x + d.y * db.y;
                 const float dv = d.x * db.z + d.y * db.w;
-                mA = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(mA, du), dv), -du - dv);
+                uA = max(max(uA, mag_bits(du)), max(mag_bits(dv), mag_bits(-du - dv)));
             }
             if (WRITE_GRAST) ((float4*)p.gradRasterDB)[pidx] = gdb;
             if (!p.dbToPos) gdb = make_float4(0.f, 0.f, 0.f, 0.f);       // rasterize(..., grad_db=False): not propagated to pos
@@ -217,11 +223,11 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
             const float fy = p.ys * (float)py + p.yo;
             raster_tape<ENABLE_DA>(P, fx, fy, p.xs, p.ys, gb0, gb1, gdb, ENABLE_DA && (((uint32_t)nz_db) << 1) != 0u, g[r]);
 #pragma unroll
-            for (int k = 0; k < 9; k++) mP = max_abs_keep_nan(mP, g[r][k]);
+            for (int k = 0; k < 9; k++) uP = max(uP, mag_bits(g[r][k]));
         }
     }
-    block_max_update(&s_max[0], mA);
-    block_max_update(&s_max[2], mP);
+    block_max_update(&s_max[0], __int_as_float((int)uA));
+    block_max_update(&s_max[2], __int_as_float((int)uP));
     __syncthreads();
     const uint32_t maxA = s_max[0], maxP = s_max[2];
     if ((maxA | maxP) == 0u) return;                        // no contribution anywhere in the block
