@@ -40,12 +40,6 @@ struct FusedParams {
     TileFlags flags;                                        // which 8x8 tiles of rast show a triangle at all, or f == nullptr
 };
 
-// Largest magnitude as BITS: for non-negative floats unsigned order is float order, inf and NaN patterns sort above every finite
-// one (so a NaN anywhere survives to the block maximum, which is what routes the block to the plain-atomic path), and the whole
-// update is one v_and + one v_max_u32 -- max_abs_keep_nan is a compare, a select, an fmax and an fabs.  This kernel runs at 95 %
-// of its vector issue rate (profiles/r04w_pmc_ch.log): instructions are its time.
-__device__ __forceinline__ uint32_t mag_bits(float v) { return (uint32_t)__float_as_int(v) & 0x7FFFFFFFu; }
-
 constexpr int kFuBlockW = 64;
 constexpr int kFuBlockH = 16;
 constexpr int kFuWaves = 8;

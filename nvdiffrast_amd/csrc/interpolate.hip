@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
     IpPixel q[kIpRowsPerWave];
     bool ok[kIpRowsPerWave];
     float4 yreg[kIpRowsPerWave];
-    float m = 0.f;
+    uint32_t um = 0u;                                       // the lane's largest contribution, as magnitude bits (nvdr_device.hpp mag_bits)
 
     // ---- phase A -----------------------------------------------------------------------
 #pragma unroll
@@ -330,14 +330,14 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
             const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
             gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
             gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
-            ymax = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y), y.z), y.w);
+            ymax = __int_as_float((int)max(max(mag_bits(y.x), mag_bits(y.y)), max(mag_bits(y.z), mag_bits(y.w))));
             yreg[r] = y;
         } else if (A_CT == 2) {                             // the usual texture-coordinate case
             const float2 y = *(const float2*)pdy;
             const float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
             gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y);
             gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y);
-            ymax = max_abs_keep_nan(max_abs_keep_nan(0.f, y.x), y.y);
+            ymax = __int_as_float((int)max(mag_bits(y.x), mag_bits(y.y)));
             yreg[r] = make_float4(y.x, y.y, 0.f, 0.f);
         } else {
             for (int i = 0; i < A; i++) {
@@ -345,11 +345,11 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
                 const float s2v = a2[i];
                 gb0 += y * (a0[i] - s2v);
                 gb1 += y * (a1[i] - s2v);
-                ymax = max_abs_keep_nan(ymax, y);
+                ymax = __int_as_float((int)max(mag_bits(ymax), mag_bits(y)));
             }
         }
         ((float4*)p.gradRaster)[pidx] = make_float4(gb0, gb1, 0.f, 0.f);
-        m = max_abs_keep_nan(m, ymax * bmax);               // >= every |b_k * dy_i| (rounding is monotone)
+        um = max(um, mag_bits(ymax * bmax));                // >= every |b_k * dy_i| (rounding is monotone); as magnitude bits (mag_bits)
 
         if (ENABLE_DA) {
             const float4 db = ((const float4*)p.rastDB)[pidx];
@@ -364,12 +364,12 @@ __global__ __launch_bounds__(kIpThreads, (ENABLE_DA && A_CT > 0) ? 6 : 8) void k
                 gdvdx += dsdv * d.x; gdvdy += dsdv * d.y;
                 const float du = d.x * db.x + d.y * db.y;
                 const float dv = d.x * db.z + d.y * db.w;
-                m = max_abs_keep_nan(max_abs_keep_nan(max_abs_keep_nan(m, du), dv), -du - dv);
+                um = max(max(um, mag_bits(du)), max(mag_bits(dv), mag_bits(-du - dv)));
             }
             ((float4*)p.gradRasterDB)[pidx] = make_float4(gdudx, gdudy, gdvdx, gdvdy);
         }
     }
-    block_max_update(s_max, m);
+    block_max_update(s_max, __int_as_float((int)um));
     __syncthreads();
     const uint32_t maxBits = *s_max;
     if (maxBits == 0u || (p.dbg & 1)) return;               // no contribution anywhere in the block

@@ -1600,21 +1600,21 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
     // Phase A: per-pixel gradients (kept in registers) and the block's largest magnitude.
     PixelGrad pg[kGradRowsPerWave];
     bool ok[kGradRowsPerWave];
-    float m = 0.f;
+    uint32_t um = 0u;                                       // (as magnitude bits: nvdr_device.hpp mag_bits)
 #pragma unroll
     for (int r = 0; r < kGradRowsPerWave; r++) {
         const int py = row0 + r;
         ok[r] = (py < p.H) && raster_pixel_grad<ENABLE_DB>(p, vb, px, py, pz, pg[r]);
         if (ok[r]) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) m = max_abs_keep_nan(m, pg[r].g[k]);
+            for (int k = 0; k < 9; k++) um = max(um, mag_bits(pg[r].g[k]));
         } else {
             pg[r].tri = -1;
 #pragma unroll
             for (int k = 0; k < 9; k++) pg[r].g[k] = 0.f;       // the run scan multiplies masked lanes by 0: keep them finite
         }
     }
-    block_max_update(&s_max, m);
+    block_max_update(&s_max, __int_as_float((int)um));
     __syncthreads();
     const uint32_t maxBits = s_max;
     if (maxBits == 0u || (p.dbg & 1)) return;                    // nothing to accumulate
