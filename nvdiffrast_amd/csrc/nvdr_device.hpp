@@ -40,6 +40,30 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
     return v;
 }
 
+// Bitwise OR over all 64 lanes; the result is valid in lane 63 (only).
+__device__ __forceinline__ uint32_t wave_or_to_last(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);           // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);          // row_shr:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);          // row_shr:8
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);          // row_bcast:15 -> rows 1, 3
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);          // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// Inclusive prefix sum over the 64 lanes, by data-parallel-primitive moves only (no LDS permutes, and no per-lane source
+// addresses for the compiler to hoist out of a loop and park somewhere): Hillis-Steele inside each row of 16 lanes (row_shr
+// fills with the "old" operand, 0, at the row's start), then the rows' totals across (row_bcast 15 / 31).
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);          // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);          // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);          // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);          // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);          // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);          // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Hardware f32 atomic add, no return value (global_atomic_add_f32).
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
@@ -65,6 +89,18 @@ __device__ __forceinline__ bool decode_block(int gx, int gy, int N, int& bx, int
     by = rem / gx;
     bx = rem - by * gx;
     return true;
+}
+
+// ---- wave-uniform loads through the scalar cache ----------------------------------------
+// A load whose address is the same in every lane (built from kernel arguments and readfirstlane'd values) of memory that
+// nothing writes during the launch: the pointer is cast into the constant address space, for which the compiler itself
+// selects s_load_dword(xN) AND tracks the outstanding load (its own s_waitcnt lgkmcnt placement).  This replaces hand-written
+// `s_load_dword` asm statements with a separate `s_waitcnt` statement, between which the register allocator was free to
+// touch the destination SGPRs (SMEM returns are not interlocked: ADVICE r4).
+template <typename T>
+__device__ __forceinline__ T scalar_load(const T* p) {
+    typedef const T __attribute__((address_space(4))) * ConstPtr;
+    return *(ConstPtr)p;
 }
 
 // ---- streaming accesses ---------------------------------------------------------------

@@ -248,6 +248,9 @@ __device__ void emit_record(const SetupParams& p, int n, int slot, const SubTri&
     size_t so = (size_t)n * p.slots + slot;
     if (x0 > x1 || y0 > y1) { if (boxStage) *boxStage = kEmptyBox; else p.bbox[so] = kEmptyBox; return; }
     uint32_t box = (uint32_t)(x0 >> 3) | ((uint32_t)(y0 >> 3) << 8) | ((uint32_t)(x1 >> 3) << 16) | ((uint32_t)(y1 >> 3) << 24);
+    // Per-bin histogram: here only for the clipper's output (stage == nullptr, rare); the common path's triangles are counted
+    // by their wave together, after the pass (hist_add_wave in k_setup).
+    if (!stage)
     for (int by_ = y0 >> 6; by_ <= (y1 >> 6); by_++)
         for (int bx_ = x0 >> 6; bx_ <= (x1 >> 6); bx_++)
         {
@@ -426,6 +429,48 @@ __device__ __forceinline__ void setup_one(const SetupParams& p, int n, int i, in
     }
 }
 
+// The wave's 64 direct slots (slot0 + lane, AABBs in `box`, tile units) into the block's bin histogram s_hist = [3][nb]: count,
+// largest slot + 1, INT_MAX - smallest slot per bin.  Neighbouring triangles lie in the same bin, so one LDS atomic per lane
+// means up to 64 serialised same-address atomics, three times over (r04: a quarter of k_setup's wave-cycles waited on LDS).  The
+// lanes of the wave's first two distinct first-bins are counted by ONE lane each -- their count is a popcount, and since the
+// slots ascend with the lane number their largest / smallest slots are those of the highest / lowest lane -- the rest, and the
+// further bins of triangles that span several, on their own.  Every lane of the wave must call it.
+__device__ __forceinline__ void hist_add_wave(int* s_hist, int nb, int binsX, uint32_t box, int slot0)
+{
+    const int lane = lane_id();
+    const bool live = (box & 255u) <= ((box >> 16) & 255u);              // (kEmptyBox / kClipBox: txlo > txhi)
+    const int x0 = (int)(box & 255u) >> 3, y0 = (int)((box >> 8) & 255u) >> 3, x1 = (int)((box >> 16) & 255u) >> 3, y1 = (int)(box >> 24) >> 3;
+    const int bf = y0 * binsX + x0;
+    uint64_t todo = __ballot(live);
+#pragma unroll 1
+    for (int it = 0; it < 2 && todo; it++) {
+        const int lead = __builtin_ctzll(todo);
+        const int b0 = __builtin_amdgcn_readlane(bf, lead);
+        const uint64_t m = __ballot(live && bf == b0) & todo;
+        if (lane == lead) {
+            atomicAdd(&s_hist[b0], (int)__popcll(m));
+            atomicMax(&s_hist[nb + b0], slot0 + (63 - __builtin_clzll(m)) + 1);
+            atomicMax(&s_hist[2 * nb + b0], 0x7FFFFFFF - (slot0 + lead));
+        }
+        todo &= ~m;
+    }
+    const int slot = slot0 + lane;
+    if ((todo >> lane) & 1ull) {
+        atomicAdd(&s_hist[bf], 1);
+        atomicMax(&s_hist[nb + bf], slot + 1);
+        atomicMax(&s_hist[2 * nb + bf], 0x7FFFFFFF - slot);
+    }
+    if (live && (x1 > x0 || y1 > y0)) {
+        for (int by = y0; by <= y1; by++)
+            for (int bx = (by == y0 ? x0 + 1 : x0); bx <= x1; bx++) {
+                const int b = by * binsX + bx;
+                atomicAdd(&s_hist[b], 1);
+                atomicMax(&s_hist[nb + b], slot + 1);
+                atomicMax(&s_hist[2 * nb + b], 0x7FFFFFFF - slot);
+            }
+    }
+}
+
 // Dynamic LDS: int s_hist[3 * binsX * binsY].
 __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int blocksPerImage)
 {
@@ -455,6 +500,7 @@ __global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int b
     __syncthreads();
     const int i0 = bxi * 256;
     setup_one(p, n, i0 + threadIdx.x, s_hist, s_rec + threadIdx.x * 4, &s_box[threadIdx.x], s_clipq, &s_clipn);
+    hist_add_wave(s_hist, nb, p.binsX, s_box[threadIdx.x], i0 + (int)(threadIdx.x & ~63u));      // (each thread reads the AABB it staged itself)
     __syncthreads();
     {
         // Slots waiting for the clipper are left out (pass 2 writes them in place).
@@ -864,14 +910,42 @@ struct FineParams {
 constexpr int kEarlyZTiles = 4;                          // tile bounds a wave refreshes per batch of 64 pairs once covered tiles see more pairs (k_fine)
 constexpr int kQueueSize = 128;
 
+// Build-time variants of k_fine's pair stage (tools/build_variant.sh passes -D flags for A/B runs on one GPU box):
+//   NVDR_FINE_DIRECT   1: a wave's 64 pairs go from the lanes that numbered them straight into raster_pairs (registers);
+//                      0: through the per-wave LDS ring of round 2-4 (a leftover of the per-tile rejection test that filtered
+//                         pairs before they were queued: with every pair kept, the ring is a write and a read back per pair)
+//   NVDR_FINE_BSTART   1: the list entry of a wave's first pair comes from a table wave 0 fills next to the prefix sum (the entry
+//                         holding every 64th pair), the other 63 from one read of the next 64 prefixes and a wave-wide OR;
+//                      0: a 9-step binary search per lane over the prefix array (nine dependent LDS round trips per batch)
+//   NVDR_FINE_FULLZ    1: a mask that covers its tile completely lowers the tile's depth bound at once (FineRaster.inl:19-34
+//                         updateTileZMax without the scan): the plane's largest corner value, one scalar computation + one ds_min_u32
+//   NVDR_FINE_COLD     while no tile of the bin has a finite bound, a wave refreshes one tile's bound every NVDR_FINE_COLD-th batch
+#ifndef NVDR_FINE_DIRECT
+#define NVDR_FINE_DIRECT 1
+#endif
+#ifndef NVDR_FINE_BSTART
+#define NVDR_FINE_BSTART 1
+#endif
+#ifndef NVDR_FINE_FULLZ
+#define NVDR_FINE_FULLZ 1
+#endif
+#ifndef NVDR_FINE_COLD
+#define NVDR_FINE_COLD 4
+#endif
+
 struct FineShared {
     uint32_t slot[kListCap];                               // bin triangle list: record slot of each entry
     uint32_t box[kListCap];                                // packed tile AABBs of the list entries
     unsigned long long key[kBinTiles][kBinTiles][64];      // per-pixel visibility keys of the bin [tileY][tileX][pixel]
     uint16_t pfx[kListCap + 64];                           // exclusive prefix of the entries' (triangle, tile) pair counts (<= 448 x 64)
     uint32_t tileZ[kBinTiles * kBinTiles];                 // per tile: an upper bound (upper half + 1) of what every pixel's depth will end up at most
+#if NVDR_FINE_DIRECT
+    uint16_t bstart[kListCap];                             // per 64 pairs: the list entry that holds pair 64 k (at most kListCap x 64 pairs)
+#else
     uint16_t queue[kFineWaves][kQueueSize];                // per-wave ring of surviving pairs: entry | tileX << 9 | tileY << 12
+#endif
     int count;
+    int pending;                                           // some wave has not scanned its share of the bin's slot range to the end
     int totalPairs;
     int ticket;                                            // rows of a partner bin handed to the waves as they finish (clear_bin)
 };
@@ -884,11 +958,10 @@ struct FineShared {
 // Bit b of the mask is pixel (x, y) = (7 - (b & 7), 7 - (b >> 3)) of the tile.
 template <bool PEEL, bool DBG = false>
 __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
-                                             int wave, int lane, int n, int head, int npairs, int btx0, int bty0,
+                                             int lane, int n, bool act, uint32_t q, int btx0, int bty0,
                                              unsigned long long* dbgNonEmpty = nullptr, bool ezOn = true)
 {
-    const bool act = lane < npairs;
-    const uint32_t q = sh.queue[wave][(head + lane) & (kQueueSize - 1)];
+    // q = list entry | tile column << 9 | tile row << 12 (inside the bin) of this lane's pair
     const int e = act ? (int)(q & 511u) : 0;
     const int tx = act ? (int)((q >> 9) & 7u) : 0;
     const int tyl = act ? (int)((q >> 12) & 7u) : 0;
@@ -999,6 +1072,17 @@ __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p
             const uint32_t szx = (uint32_t)__builtin_amdgcn_readlane((int)zx, src), szy = (uint32_t)__builtin_amdgcn_readlane((int)zy, src);
             const uint32_t sd0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, src), sidk = (uint32_t)__builtin_amdgcn_readlane((int)idk, src);
             const int stile = __builtin_amdgcn_readlane(tile, src);
+#if NVDR_FINE_FULLZ
+            if (!PEEL && ezOn && sm == ~0ull) {
+                // The triangle covers all 64 pixels of the tile: every pixel's key ends up at most at this triangle's depth there,
+                // so the plane's largest corner value bounds the tile at once (the reference's updateTileZMax, FineRaster.inl:19-34,
+                // without its scan; not while peeling, where a fragment may be rejected by the previous layer).  All four corners
+                // are covered pixels, so their depths are true plane values (no wrap) and 7 |slope| < 2^32 makes the signed reading
+                // of the slopes the right one.  Scalar arithmetic; one lane lowers the bound.
+                const uint32_t cmax = sd0 + 7u * (uint32_t)max((int)szx, 0) + 7u * (uint32_t)max((int)szy, 0);
+                if (lane == 0) atomicMin(&sh.tileZ[stile], (cmax >> 16) + 1u);
+            }
+#endif
             if (__builtin_amdgcn_inverse_ballot_w64(sm)) {                 // the mask IS the execution mask
                 const uint32_t depth = sd0 + __umul24(szx & 0xFFFFFFu, xl) + (__umul24(szx >> 24, xl) << 24)
                                            + __umul24(szy & 0xFFFFFFu, yl) + (__umul24(szy >> 24, yl) << 24);
@@ -1031,7 +1115,7 @@ __device__ __forceinline__ void refresh_tile_bound(FineShared& sh, int tile)
     d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x118, 0xf, 0xf, false));     // row_shr:8
     d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x142, 0xa, 0xf, false));     // row_bcast:15 -> rows 1, 3
     d = max(d, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x143, 0xc, 0xf, false));     // row_bcast:31 -> rows 2, 3
-    if (l == 63) sh.tileZ[tile] = (d >> 16) + 1u;                                             // (upper half, rounded up)
+    if (l == 63) atomicMin(&sh.tileZ[tile], (d >> 16) + 1u);                                  // (upper half, rounded up; a minimum: a full-tile bound may be lower already)
 }
 
 // DBG = development instrumentation (per-workgroup phase timestamps and experiment switches); the
@@ -1047,6 +1131,10 @@ template <bool PEEL, bool WRITE_DEPTH, bool DBG, bool SPLIT, bool LIST = false, 
 __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fine(const FineParams p)
 {
     __shared__ FineShared sh;
+    // The thread id is used HERE and nowhere below: the wave number lives in a scalar register, lane numbers come from v_mbcnt
+    // wherever they are needed, and "thread 0" is lane 0 of wave 0 -- kept as a VGPR across the raster stage the packed id register
+    // was parked in scratch (r04: 12 B/lane; tests/test_kernel_resources.py).
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // Work assignment.  Blocks b, b+8, b+16, ... run on one XCD (observed b % 8 placement)
     // and walk that XCD's chunk of the heavy-first order produced by k_order, so an image's
@@ -1115,10 +1203,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         if (jj - nz < nz) return;                                          // cleared by the chunk's (jj - nz)-th bin
         // an empty bin without a partner (more empty bins than others in the chunk): zeros straight away -- no key arrays, no
         // shader; its waves take their tile rows from a ticket like the partner-clearing epilogue does
-        if (threadIdx.x == 0) sh.ticket = 0;
+        if (wave == 0 && lane_id() == 0) sh.ticket = 0;
         __syncthreads();
         int row = 0;
-        if ((threadIdx.x & 63) == 0) row = atomicAdd(&sh.ticket, 1);
+        if (lane_id() == 0) row = atomicAdd(&sh.ticket, 1);
         clear_bin(it4.z, __builtin_amdgcn_readfirstlane(row));
         return;
     }
@@ -1128,8 +1216,8 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const int btx0 = binX * kBinTiles, bty0 = binY * kBinTiles;
     const int binTris = SHADE ? 0 : (SPLIT && parts > 1) ? 0x7FFFFFFF : it4.y;   // triangles whose AABB touches this bin (a part does not know its share: it scans its whole range)
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const bool first = wave == 0 && lane == 0;
     const int vpwPad = (p.vp.vpw + 7) & ~7, vphPad = (p.vp.vph + 7) & ~7;
 
     unsigned long long tstamp[6] = {0, 0, 0, 0, 0, 0};
@@ -1138,7 +1226,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     const unsigned long long kInit = ((unsigned long long)kDepthMax << 32) | 0xFFFFFFFFull;
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; t++) sh.key[wave / kWavesPerRow][(wave % kWavesPerRow) * kTilesPerWave + t][lane] = kInit;
-    if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; sh.ticket = 0; }
+    if (first) { sh.count = 0; sh.slot[0] = 0; sh.ticket = 0; sh.pending = 0; }
     if (wave == 0) sh.tileZ[lane] = 0xFFFFFFFFu;
     __syncthreads();
 
@@ -1198,12 +1286,13 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (listMode && !done) {
                 // ---- the next kListCap entries of the bin's list, with their AABBs ----------
                 const int take = min(kListCap, total - scan);
-                if ((int)threadIdx.x < take) {
-                    const uint32_t slot = p.binList[(size_t)(uint32_t)scanLo + scan + threadIdx.x];
-                    sh.slot[threadIdx.x] = slot;
-                    sh.box[threadIdx.x] = gbox[slot];
+                const int tid = wave * 64 + lane;
+                if (tid < take) {
+                    const uint32_t slot = p.binList[(size_t)(uint32_t)scanLo + scan + tid];
+                    sh.slot[tid] = slot;
+                    sh.box[tid] = gbox[slot];
                 }
-                if (threadIdx.x == 0) sh.count = take;
+                if (first) sh.count = take;
                 scan += take;
                 done = (scan >= total);
             }
@@ -1244,11 +1333,14 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 cur = nxt;
             }
             unsigned long long tf0 = (DBG && p.dbgbuf) ? wall_clock64() : 0;
+            // The bin is finished when every wave has scanned to the end or all its triangles are listed: a wave that is not at
+            // its end says so (one LDS word, reset between the passes) -- __syncthreads_and() is a second barrier and computes the
+            // flat thread id from all three id components, which kept the packed id register alive across the kernel.
+            if (!done && lane == 0) sh.pending = 1;
             __syncthreads();
             const int cnt = min(sh.count, kListCap);
             found += cnt;
-            // The bin is finished when every wave has scanned to the end or all its triangles are listed.
-            const int allDone = __builtin_amdgcn_readfirstlane(__syncthreads_and((done || found >= binTris) ? 1 : 0));   // uniform: keep it in an SGPR
+            const int allDone = __builtin_amdgcn_readfirstlane((found >= binTris || sh.pending == 0) ? 1 : 0);   // uniform: keep it in an SGPR
             unsigned long long tf1 = (DBG && p.dbgbuf) ? wall_clock64() : 0;
             if (DBG) { tstamp[1] += 1; tstamp[4] += cnt; }
 
@@ -1279,23 +1371,88 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     local[i] = sum;
                     sum += nx * ny;
                 }
-                int incl = sum;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                const int incl = wave_scan_incl(sum);
                 const int base = incl - sum;
 #pragma unroll
                 for (int i = 0; i < kPer; i++) { const int j = lane * kPer + i; if (j <= cnt) sh.pfx[j] = (uint16_t)(base + local[i]); }
+#if NVDR_FINE_DIRECT && NVDR_FINE_BSTART
+                // the entry that holds every 64th pair: entry j covers pairs [start, end); the first multiple of 64 at or after its
+                // start is inside it at most once (an entry has at most 64 pairs)
+#pragma unroll
+                for (int i = 0; i < kPer; i++) {
+                    const int j = lane * kPer + i;
+                    const int start = base + local[i], end = (i + 1 < kPer) ? base + local[(i + 1) % kPer] : incl;
+                    const int k64 = (start + 63) >> 6;
+                    if (j < cnt && (k64 << 6) < end) sh.bstart[k64] = (uint16_t)j;
+                }
+#endif
                 if (lane == 63) sh.totalPairs = incl;
             }
             __syncthreads();
             if (!(DBG && (p.dbg & 4))) {
                 const int total = sh.totalPairs;
-                int head = 0, qn = 0;
-                // (NVDR_DEBUG 32: the kernel without its depth cull, for comparison.  Not in the list instantiation: a mesh of 32 k+
-                // triangles is a mesh of small triangles -- little fragment work to save -- and the cull's registers cost that
-                // instantiation 8 % at a million triangles, 0.245 -> 0.263 ms)
-                const bool ezOn = !LIST && !(p.dbg & 32);
+                // (NVDR_DEBUG 32, debug instantiation: the kernel without its depth cull, for comparison.  Not in the list
+                // instantiation: a mesh of 32 k+ triangles is a mesh of small triangles -- little fragment work to save -- and the
+                // cull's registers cost that instantiation 8 % at a million triangles, 0.245 -> 0.263 ms)
+                const bool ezOn = !LIST && !(DBG && (p.dbg & 32));
                 int turn = wave;                            // the tile whose depth bound this wave refreshes next
+#if NVDR_FINE_DIRECT
+                int cold = 0;                               // batches since this wave last refreshed a bound with nothing to cull
+                for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
+                    const int q = q0 + lane;
+                    const bool act = q < total;
+                    int j;
+#if NVDR_FINE_BSTART
+                    {
+                        // entry s holds pair q0 (wave 0's table); the entries s + 1 ... that START inside this batch each set one
+                        // bit of a wave-wide mask (entries have at least one pair each: starts are distinct), and a pair's entry is s
+                        // + the number of starts at or below it
+                        const int s = __builtin_amdgcn_readfirstlane((int)sh.bstart[q0 >> 6]);
+                        const int el = s + lane;
+                        const int r = (lane >= 1 && el <= cnt) ? (int)sh.pfx[el] - q0 : 64;        // (pfx[cnt] = total: no start there)
+                        const bool st = r < 64 && el < cnt;
+                        uint32_t blo = (st && r < 32) ? 1u << r : 0u, bhi = (st && r >= 32) ? 1u << (r - 32) : 0u;
+                        blo = wave_or_to_last(blo); bhi = wave_or_to_last(bhi);
+                        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)blo, 63), mhi = (uint32_t)__builtin_amdgcn_readlane((int)bhi, 63);
+                        // starts at positions <= lane: those strictly below (mbcnt) + this lane's own
+                        const uint64_t M = ((uint64_t)mhi << 32) | mlo;
+                        j = s + mask_rank(M) + (int)((M >> lane) & 1ull);
+                        if (!act) j = 0;
+                    }
+#else
+                    {
+                        // entry j = the last one whose prefix is <= q (entries without pairs share a prefix
+                        // with their successor and are skipped by taking the last)
+                        int lo = 0, hi = cnt - 1;
+                        while (__ballot(lo < hi)) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (lo < hi) { if ((int)sh.pfx[mid] <= q) lo = mid; else hi = mid - 1; }
+                        }
+                        j = act ? lo : 0;
+                    }
+#endif
+                    int x0, y0, nx, ny;
+                    pair_box(sh.box[j], x0, y0, nx, ny);
+                    const int k = act ? q - (int)sh.pfx[j] : 0;
+                    const int ky = (nx > 1) ? (int)(((float)k + 0.5f) / (float)nx) : k;   // exact for k < 64, nx <= 8
+                    const int kx = k - ky * nx;
+                    const int tx = x0 + kx - btx0, tyl = y0 + ky - bty0;
+                    const bool hotBatch = raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, act, (uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12),
+                                                                  btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
+                    // (kEarlyZTiles tiles per batch once covered tiles see more pairs; while nothing is there to cull, one tile
+                    // every NVDR_FINE_COLD batches: a scene without overdraw pays next to nothing)
+                    if (ezOn) {
+                        int nref = hotBatch ? kEarlyZTiles : 0;
+                        if (!hotBatch && ++cold >= NVDR_FINE_COLD) { cold = 0; nref = 1; }
+#pragma unroll 1
+                        for (int rt = 0; rt < nref; rt++) {
+                            refresh_tile_bound(sh, turn);
+                            turn = (turn + kFineWaves) & (kBinTiles * kBinTiles - 1);
+                        }
+                    }
+                }
+#else
+                int head = 0, qn = 0;
                 for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
                     const int q = q0 + lane;
                     const bool act = q < total;
@@ -1320,8 +1477,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     qn += __popcll(m);
                     if (qn >= 64) {
                         __builtin_amdgcn_wave_barrier();
-                        const bool hotBatch = raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, 64, btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
-                        (void)hotBatch;
+                        const bool hotBatch = raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, true, sh.queue[wave][(head + lane) & (kQueueSize - 1)], btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
                         __builtin_amdgcn_wave_barrier();
                         head = (head + 64) & (kQueueSize - 1);
                         qn -= 64;
@@ -1335,14 +1491,20 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 }
                 if (qn > 0) {
                     __builtin_amdgcn_wave_barrier();
-                    raster_pairs<PEEL, DBG>(sh, p, grec, wave, lane, n, head, qn, btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
+                    raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, lane < qn, sh.queue[wave][(head + lane) & (kQueueSize - 1)], btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
                     __builtin_amdgcn_wave_barrier();
                 }
+#endif
             }
             if (DBG && p.dbgbuf) { unsigned long long tr = wall_clock64(); if (p.dbg & 64) { tstamp[2] += (unsigned long long)sh.totalPairs; tstamp[3] += dbgSurv; dbgSurv = 0; } else { tstamp[2] += tf1 - tf0; tstamp[3] += tr - tf1; } }
             __syncthreads();
             if (allDone) break;
-            if (threadIdx.x == 0) { sh.count = 0; sh.slot[0] = 0; }
+            if (first) {
+                // (the zero is made in place, opaque to the compiler: as a constant it was hoisted out of the pass loop as a 64-bit
+                // pair for the two neighbouring words -- and, there being no registers for it, parked in scratch)
+                int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                sh.count = z; sh.slot[0] = (uint32_t)z; sh.pending = z;
+            }
             __syncthreads();
         }
     }
@@ -1395,12 +1557,10 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         // The arrival counter carries the hand-off in the memory model's terms as well: release (this part's keys are
         // visible before its count) and acquire (the last part sees the others' keys after reading the full count), at
         // agent scope, by ONE thread of the shared bins' workgroups only -- not the per-wave fences in every workgroup
-        // that cost 126 -> 220 us in round 2.  NVDR_DEBUG bit 4194304 selects the relaxed form (timing comparison).
-        if (threadIdx.x == 0) {
+        // that cost 126 -> 220 us in round 2 (measured in round 3 at batch 16: k_fine 58 us relaxed, 63 us release-only, 64 us as here).
+        if (first) {
             const int add = 1 + (landed >> 8);
-            const int before = (p.dbg & 4194304) ? atomicAdd(&p.splitDone[split], add)
-                             : (p.dbg & 8388608) ? __hip_atomic_fetch_add(&p.splitDone[split], add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
-                                                 : __hip_atomic_fetch_add(&p.splitDone[split], add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            const int before = __hip_atomic_fetch_add(&p.splitDone[split], add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             sh.count = (before == parts - 1) ? 1 : 0;
         }
         __syncthreads();

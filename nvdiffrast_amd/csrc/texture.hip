@@ -473,19 +473,12 @@ __global__ __launch_bounds__(256) void k_tex_fwd(const TexParams p)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int tc = __builtin_amdgcn_readfirstlane(q0.tc[k]);
+            // wave-uniform address: scalar loads (selected and waited for by the compiler, nvdr_device.hpp scalar_load); a tap
+            // without a texel reads texel 0 and is zeroed afterwards, so that all loads are in flight together
+            const float* tp = p.tex[0] + (size_t)max(tc, 0) * CMAX;
 #pragma unroll
-            for (int c = 0; c < CMAX; c++) a[k][c] = 0.f;
-            if (tc >= 0) {
-                const float* tp = p.tex[0] + (size_t)tc * CMAX;                        // wave-uniform address: scalar loads
-#pragma unroll
-                for (int c = 0; c < CMAX; c++) asm volatile("s_load_dword %0, %1, %2" : "=s"(a[k][c]) : "s"(tp), "n"(c * 4) : "memory");
-            }
+            for (int c = 0; c < CMAX; c++) { const float t = scalar_load(tp + c); a[k][c] = tc >= 0 ? t : 0.f; }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int c = 0; c < CMAX; c++) asm volatile("" : "+s"(a[k][c]));          // (every use of the loaded values stays behind the wait)
 #pragma unroll
         for (int c = 0; c < CMAX; c++) ur[c] = bilerp1(a[0][c], a[1][c], a[2][c], a[3][c], q0.fu, q0.fv);
         haveU = true;
@@ -1235,9 +1228,8 @@ __global__ __launch_bounds__(256, 8) void k_tex_grad_light_w(const TexParams p, 
         const bool row0 = haveF && ty8 < p.zflags.h, row1 = haveF && ty8 + 1 < p.zflags.h;
         const uint32_t* wp0 = (const uint32_t*)p.zflags.f + (f0 >> 2);
         const uint32_t* wp1 = (const uint32_t*)p.zflags.f + (f1 >> 2);
-        if (row0) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(w0) : "s"(wp0) : "memory");
-        if (row1) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(w1) : "s"(wp1) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(w0), "+s"(w1) :: "memory");
+        if (row0) w0 = scalar_load(wp0);
+        if (row1) w1 = scalar_load(wp1);
         const uint32_t s0 = (uint32_t)(f0 & 3) * 8u, s1 = (uint32_t)(f1 & 3) * 8u;
         const bool col1 = tx8 + 1 < p.zflags.w;
         ztile[0] = row0 && ((w0 >> s0) & 0xFFu) == 0u;
@@ -1333,19 +1325,11 @@ __global__ __launch_bounds__(256, 8) void k_tex_grad_light_w(const TexParams p, 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             qtc[k] = __builtin_amdgcn_readfirstlane(q0.tc[k]);
+            // wave-uniform address: scalar loads (nvdr_device.hpp scalar_load); a tap without a texel reads texel 0 and is zeroed
+            const float* tp = pIn0 + (size_t)max(qtc[k], 0) * C;
 #pragma unroll
-            for (int c = 0; c < C; c++) qa[k][c] = 0.f;
-            if (qtc[k] >= 0) {
-                const float* tp = pIn0 + (size_t)qtc[k] * C;                       // wave-uniform address: scalar loads
-#pragma unroll
-                for (int c = 0; c < C; c++) asm volatile("s_load_dword %0, %1, %2" : "=s"(qa[k][c]) : "s"(tp), "n"(c * 4) : "memory");
-            }
+            for (int c = 0; c < C; c++) { const float t = scalar_load(tp + c); qa[k][c] = qtc[k] >= 0 ? t : 0.f; }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int c = 0; c < C; c++) asm volatile("" : "+s"(qa[k][c]));          // (every use of the loaded values stays behind the wait)
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const float ad = (qa[3][c] + qa[0][c] - qa[1][c] - qa[2][c]);

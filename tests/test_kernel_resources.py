@@ -47,15 +47,19 @@ def _metadata(tmp_path, src):
 def test_rasterizer_kernels_stay_within_their_budgets(tmp_path):
     k = _metadata(tmp_path, "raster.hip")
     fine = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb0ELb0ELb0EEEvNS_10FineParamsE"]       # production: no peel, no depth surface, no debug, no sharing, no lists
-    # 8 waves/SIMD, 4 workgroups/CU.  Three registers that live across the whole kernel (thread id, the bin's slot range) are parked
-    # in scratch at its start since the per-tile depth cull (r04): stored once per workgroup pass, none inside the pair loop
-    assert fine[0] <= 12 and fine[1] <= 64, fine
+    # 8 waves/SIMD, 4 workgroups/CU, no scratch (r04 parked the packed thread id and two hoisted values: 12 B/lane; r05 takes the
+    # thread id apart at the kernel's first instruction, replaces __syncthreads_and -- which needs the flat id -- by one LDS word,
+    # and scans with DPP moves instead of __shfl_up, whose per-lane source addresses were hoisted out of the pass loop)
+    assert fine[0] == 0 and fine[1] <= 64, fine
     shared = k["_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb0ELb0EEEvNS_10FineParamsE"]
-    assert shared[1] <= 64 and shared[0] <= 16, shared
+    assert shared[1] <= 64 and shared[0] == 0, shared
     for name in ("_ZN4nvdr6k_fineILb0ELb0ELb0ELb0ELb1ELb0EEEvNS_10FineParamsE", "_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb1ELb0EEEvNS_10FineParamsE",
                  "_ZN4nvdr6k_fineILb0ELb0ELb0ELb1ELb1ELb1EEEvNS_10FineParamsE"):
         lists = k[name]                                                         # large meshes: bins with triangle lists
-        assert lists[1] <= 64 and lists[0] <= 32, (name, lists)
+        assert lists[1] <= 64 and lists[0] == 0, (name, lists)
+    for name, v in k.items():                                                   # depth peeling / depth surface: every instantiation at 8 waves/SIMD
+        if re.search(r"k_fineILb[01]ELb[01]ELb0E", name):                         # (all but the debug instantiations)
+            assert v[1] <= 64 and v[0] <= 16, (name, v)
     grad = k["_ZN4nvdr13k_raster_gradILb0EEEvNS_10GradParamsEii"]
     assert grad[0] == 0 and grad[1] <= 80, grad                                 # 6 waves/SIMD
     setup = k["_ZN4nvdr7k_setupENS_11SetupParamsEi"]
@@ -113,3 +117,23 @@ def test_shared_bin_handoff_waits_for_its_exchanges_before_the_barrier(tmp_path)
         # forms the timing switches select (raster.hip)
         windows = [" ".join(l.strip() for l in body[i:i + 5]) for i in range(barrier, len(body)) if "buffer_wbl2" in body[i]]
         assert any("global_atomic_add" in w and "buffer_inv" in w for w in windows), (name, windows)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_wave_uniform_texel_loads_are_scalar_loads_the_compiler_tracks(tmp_path):
+    """the uniform-tile sample of k_tex_fwd and the flags / constant quad of k_tex_grad_light_w were fetched by
+    hand-written `s_load_dword` asm statements with the `s_waitcnt` in a SEPARATE statement -- nothing kept the register
+    allocator from touching the destination SGPRs in between (SMEM returns are not interlocked).  They are now ordinary
+    loads through a constant-address-space pointer (nvdr_device.hpp scalar_load): the compiler selects the scalar loads and
+    places the waits itself.  No source may contain an s_load asm statement, and the two kernels must still fetch those
+    values through the scalar cache (s_load from a base that is not the kernarg pointer s[0:1])."""
+    for f in os.listdir(CSRC):
+        text = open(os.path.join(CSRC, f)).read()
+        assert not re.search(r'asm[^;]*"[^"]*s_load', text), f
+        assert not re.search(r'asm[^;]*"[^"]*s_waitcnt lgkmcnt', text), f
+    text = _assembly(tmp_path, "texture.hip")
+    for name, least in (("_ZN4nvdr9k_tex_fwdILi3ELb0ELi3EEEvNS_9TexParamsE", 8), ("_ZN4nvdr18k_tex_grad_light_wILi3ELi3EEEvNS_9TexParamsEii", 8)):
+        i = text.index("\n" + name + ":")
+        body = text[i:text.index(".Lfunc_end", i)]
+        loads = [l for l in body.split("\n") if re.search(r"s_load_dword(x[234])?\s", l) and "s[0:1]" not in l]
+        assert len(loads) >= least, (name, len(loads))

@@ -21,6 +21,8 @@ def scene(name):
         return dense_batch(64), 512
     if name == "ch":
         return m10k_batch(64), 512
+    if name == "c2":
+        return m10k_batch(16), 512
     if name == "s10k":
         b = stress_triangles(64, T=10000, res=512)
         b["attr"] = np.random.default_rng(3).uniform(size=(1, b["pos"].shape[1], 4)).astype(np.float32)
@@ -52,7 +54,7 @@ def run(name, steps=10, check=True):
     for _ in range(steps): rast = step()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
     lib = _capi.load(); lib.nvdr_profile_reset(); lib.nvdr_profile_enable(1)
-    for _ in range(3): step()
+    for _ in range(10): step()
     torch.cuda.synchronize(); prof = _capi.profile_read(); lib.nvdr_profile_enable(0); lib.nvdr_profile_reset()
     doc = {"regime": name, "items": N, "res": R, "triangles": int(tri.shape[0]), "ms_per_step": round(ms, 4),
            "Gpix_per_s": round(N * R * R / ms / 1e6, 2), "coverage": round(float((rast[..., 3] > 0).float().mean()), 4),
@@ -68,5 +70,6 @@ def run(name, steps=10, check=True):
 
 
 if __name__ == "__main__":
-    for nm in (sys.argv[1:] or ["ch", "dense", "s10k", "t1m", "t1m_shuffled"]):
-        run(nm)
+    names = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for nm in (names or ["ch", "dense", "s10k", "t1m", "t1m_shuffled"]):
+        run(nm, check="--no-check" not in sys.argv)
