@@ -921,12 +921,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        detail = args.detail or os.path.join(ROOT, "bench_detail.json")
-        try:
-            with open(detail, "w") as f:
-                json.dump(result, f, indent=1)
-        except OSError:
-            detail = None
+        # (a CPU dry run -- the test suite's -- leaves no record next to this file unless asked for one with --detail)
+        detail = args.detail or (None if args.dry_run_cpu else os.path.join(ROOT, "bench_detail.json"))
+        if detail:
+            try:
+                with open(detail, "w") as f:
+                    json.dump(result, f, indent=1)
+            except OSError:
+                detail = None
         line = compact_line(result, detail)
         os.write(json_fd, (line + "\n").encode())
     os.close(json_fd)

@@ -146,7 +146,8 @@ int nvdr_interpolate_grad(const float* attr, const float* rast, const int32_t* t
  * gradient to the rasterizer's backward in registers.
  *   g_attr (shape of attr) and g_pos (shape of pos) must be zero-filled by the caller, as for the two separate calls;
  *   g_rast [N,H,W,4] = what interpolate_grad would have written, or NULL to skip it (only legal when nothing else
- *   consumes the gradient of `rast`; the operator layer always asks for it, see nvdiffrast_amd/torch/ops.py).
+ *   consumes the gradient of `rast`; the operator layer passes NULL and hands autograd a stand-in that computes the
+ *   tensor only if somebody looks at it, nvdiffrast_amd/torch/ops.py `_LazyGrad`).
  * attr_instance / attr_n as for nvdr_interpolate_grad; pos_instance != 0: pos [N,V,4], else pos [V,4] (range mode).
  * Results equal those of the two separate calls up to the summation order of the f32 atomics.
  * With pixel differentials (rast_db and dda given, diff_all / diff_attrs_host / num_diff as for nvdr_interpolate_grad) it is

@@ -51,8 +51,19 @@ int tune_int(const char* name, int fallback) {
     static std::vector<std::pair<std::string, int>> seen;
     std::lock_guard<std::mutex> l(mu);
     for (auto& kv : seen) if (kv.first == name) return kv.second;
+    // Tuning switches select variants the test suite does not run: they are honoured only in a development
+    // session (NVDR_DEV=1 in the environment), and never silently.
     const char* e = getenv(name);
-    const int v = e ? atoi(e) : fallback;
+    int v = fallback;
+    if (e) {
+        const char* dev = getenv("NVDR_DEV");
+        if (dev && atoi(dev) != 0) {
+            v = atoi(e);
+            if (v != fallback) fprintf(stderr, "[nvdr] WARNING: %s=%d (default %d): a development variant is active\n", name, v, fallback);
+        } else {
+            fprintf(stderr, "[nvdr] %s is set but ignored: tuning switches need NVDR_DEV=1\n", name);
+        }
+    }
     seen.emplace_back(name, v);
     return v;
 }

@@ -919,7 +919,9 @@ constexpr int kQueueSize = 128;
 //                      0: a 9-step binary search per lane over the prefix array (nine dependent LDS round trips per batch)
 //   NVDR_FINE_FULLZ    1: a mask that covers its tile completely lowers the tile's depth bound at once (FineRaster.inl:19-34
 //                         updateTileZMax without the scan): the plane's largest corner value, one scalar computation + one ds_min_u32
+//   NVDR_FINE_PK16     1: coverage of two pixels per instruction in 16-bit halves (raster_pairs); 0: one pixel per 32-bit step
 //   NVDR_FINE_COLD     while no tile of the bin has a finite bound, a wave refreshes one tile's bound every NVDR_FINE_COLD-th batch
+//   NVDR_FINE_ADAPT    1: ... and after every batch that held a mask with more than eight fragments
 #ifndef NVDR_FINE_DIRECT
 #define NVDR_FINE_DIRECT 1
 #endif
@@ -929,8 +931,14 @@ constexpr int kQueueSize = 128;
 #ifndef NVDR_FINE_FULLZ
 #define NVDR_FINE_FULLZ 1
 #endif
+#ifndef NVDR_FINE_PK16
+#define NVDR_FINE_PK16 1
+#endif
 #ifndef NVDR_FINE_COLD
-#define NVDR_FINE_COLD 4
+#define NVDR_FINE_COLD 8
+#endif
+#ifndef NVDR_FINE_ADAPT
+#define NVDR_FINE_ADAPT 1
 #endif
 
 struct FineShared {
@@ -955,9 +963,11 @@ struct FineShared {
 //     centres of its tile (integer adds only) and packs the signs into a 64-bit mask;
 //  2. fragments: each lane pops the set bits of its mask, evaluates the U32 depth plane
 //     and merges depth<<32|~id into the tile's key array with an LDS 64-bit atomic min.
-// Bit b of the mask is pixel (x, y) = (7 - (b & 7), 7 - (b >> 3)) of the tile.
+// Bit b of the mask is pixel (x, y) = (b & 7, b >> 3) of the tile.
+// Returns bit 0: some pair of the batch belongs to a tile with a finite depth bound (the cull ran); bit 1: the batch held a mask
+// with more than kCoop fragments (large triangles: the scenes in which tiles get covered and bounds pay).
 template <bool PEEL, bool DBG = false>
-__device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
+__device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p, const uint4* __restrict__ grec,
                                              int lane, int n, bool act, uint32_t q, int btx0, int bty0,
                                              unsigned long long* dbgNonEmpty = nullptr, bool ezOn = true)
 {
@@ -1007,21 +1017,74 @@ __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p
             if (cand && (lb >> 16) >= bound) { e0 = 0x80000000u; A0 = 0; B0 = 0; }
         }
     }
-    const bool kHot = hot;
-    if (DBG && (p.dbg & 256)) { if (q0.x == 0x12345u && q3.w == 77u) sh.key[0][0][lane] = q1.x; return false; }      // experiment: no coverage, no fragments
-    uint32_t mhi = 0, mlo = 0;                   // rows 0..3 -> mhi, rows 4..7 -> mlo (sign bits = outside)
+    const int kHot = hot ? 1 : 0;
+    if (DBG && (p.dbg & 256)) { if (q0.x == 0x12345u && q3.w == 77u) sh.key[0][0][lane] = q1.x; return 0; }      // experiment: no coverage, no fragments
+    // Coverage.  Bit y * 8 + x of the mask is pixel (x, y) of the tile.
+    uint64_t m;
+#if NVDR_FINE_PK16
+    // Two pixels per instruction, in 16-bit halves.  A, B are multiples of 16 (emit_record), so with C = 16 c1 + c0, 0 <= c0 < 16,
+    // E >= 0  <=>  E' = c1 + (A/16) X + (B/16) Y >= 0: four bits less.  Only the SIGN of E' matters, and over the tile's pixels E'
+    // moves by at most 7 (|A'| + |B'|) from its value at the origin, so that value can be clamped to +-16000 as long as that
+    // excursion stays below 14000 (|A'| + |B'| <= 2000: edges up to 125 px): a clamped start stays 2000 away from zero on its side,
+    // an unclamped one is exact, and nothing leaves the 16-bit range.  Low half = rows 0..3, high half = rows 4..7 (own start values,
+    // clamped separately); a wave holding a longer edge walks in 32 bits as before.
+    const int a0 = A0 >> 4, b0 = B0 >> 4, a1 = A1 >> 4, b1 = B1 >> 4, a2 = A2 >> 4, b2 = B2 >> 4;
+    const bool smallEdges = !act || (abs(a0) + abs(b0) <= 2000 && abs(a1) + abs(b1) <= 2000 && abs(a2) + abs(b2) <= 2000);
+    if (__ballot(!smallEdges) == 0ull) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        auto pack = [](int lo, int hi) -> uint32_t { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); };
+        auto start = [&](uint32_t e, int b) -> uint32_t {
+            const int v = (int)e >> 4;
+            return pack(min(max(v, -16000), 16000), min(max(v + 4 * b, -16000), 16000));
+        };
+        auto add2 = [](uint32_t x, uint32_t y) -> uint32_t { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, x) + __builtin_bit_cast(us2, y))); };
+        auto shr2 = [](uint32_t x) -> uint32_t { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, x) >> (us2)(1))); };
+        uint32_t r0 = start(e0, b0), r1 = start(e1, b1), r2 = start(e2, b2);
+        const uint32_t sx0 = pack(a0, a0), sx1 = pack(a1, a1), sx2 = pack(a2, a2);
+        const uint32_t sy0 = pack(b0 - 7 * a0, b0 - 7 * a0), sy1 = pack(b1 - 7 * a1, b1 - 7 * a1), sy2 = pack(b2 - 7 * a2, b2 - 7 * a2);
+        uint32_t accA = 0u, accB = 0u;              // rows {0,1 | 4,5} and {2,3 | 6,7}: sign bits (= outside) enter at the top of each half
 #pragma unroll
-    for (int y = 0; y < 8; y++) {
-        uint32_t r0 = e0, r1 = e1, r2 = e2, bits = (y < 4) ? mhi : mlo;
+        for (int rp = 0; rp < 4; rp++) {
+            uint32_t acc = rp < 2 ? accA : accB;
 #pragma unroll
-        for (int x = 0; x < 8; x++) {
-            bits = __builtin_amdgcn_alignbit(bits, r0 | r1 | r2, 31);     // (bits << 1) | sign
-            r0 += (uint32_t)A0; r1 += (uint32_t)A1; r2 += (uint32_t)A2;
+            for (int x = 0; x < 8; x++) {
+                acc = shr2(acc) | ((r0 | r1 | r2) & 0x80008000u);
+                if (x < 7) { r0 = add2(r0, sx0); r1 = add2(r1, sx1); r2 = add2(r2, sx2); }
+            }
+            if (rp < 2) accA = acc; else accB = acc;
+            if (rp < 3) { r0 = add2(r0, sy0); r1 = add2(r1, sy1); r2 = add2(r2, sy2); }
         }
-        if (y < 4) mhi = bits; else mlo = bits;
-        e0 += (uint32_t)B0; e1 += (uint32_t)B1; e2 += (uint32_t)B2;
+        const uint32_t outLo = __builtin_amdgcn_perm(accB, accA, 0x05040100u);      // rows 0..3
+        const uint32_t outHi = __builtin_amdgcn_perm(accB, accA, 0x07060302u);      // rows 4..7
+        m = act ? ~(((uint64_t)outHi << 32) | outLo) : 0ull;
+    } else
+#endif
+    {
+        // one pixel per step in 32 bits (NVDR_FINE_PK16: the rare wave that holds an edge longer than 125 px -- rolled up, so that
+        // it costs the common path neither registers nor code)
+        uint32_t half[2] = {0u, 0u};             // rows 0..3, rows 4..7 (sign bits = outside), first pixel in the top bit
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint32_t bits = 0u;
+#if NVDR_FINE_PK16
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+            for (int y = 0; y < 4; y++) {
+                uint32_t r0 = e0, r1 = e1, r2 = e2;
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    bits = __builtin_amdgcn_alignbit(bits, r0 | r1 | r2, 31);     // (bits << 1) | sign
+                    r0 += (uint32_t)A0; r1 += (uint32_t)A1; r2 += (uint32_t)A2;
+                }
+                e0 += (uint32_t)B0; e1 += (uint32_t)B1; e2 += (uint32_t)B2;
+            }
+            half[h] = bits;
+        }
+        // (this walk leaves pixel (x, y) in bit 63 - (y * 8 + x): reversed into the mask's order)
+        m = act ? ~(((uint64_t)__builtin_bitreverse32(half[1]) << 32) | __builtin_bitreverse32(half[0])) : 0ull;
     }
-    uint64_t m = act ? ~(((uint64_t)mhi << 32) | mlo) : 0ull;
     if (DBG && dbgNonEmpty) *dbgNonEmpty += __popcll(__ballot(m != 0));
     if (__ballot(m != 0) == 0) return kHot;
     if (DBG && (p.dbg & 128)) { if (m == 0x123456789ull) sh.key[0][0][lane] = m; return kHot; }                       // experiment: no fragment loop
@@ -1038,6 +1101,7 @@ __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p
     constexpr int kCoop = 8;
     const bool big = __popcll(m) > kCoop;
     uint64_t heavy = __ballot(big);
+    const int kBig = heavy ? 2 : 0;
     if (__ballot(!big && m != 0) && !(DBG && (p.dbg & 8192))) {
         const uint32_t zxl = zx & 0xFFFFFFu, zxh = zx >> 24, zyl = zy & 0xFFFFFFu, zyh = zy >> 24;
         unsigned long long* keys = sh.key[tyl][tx];
@@ -1048,7 +1112,7 @@ __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p
             if (ml != 0) {
                 int b = (__builtin_ctzll(ml) + rot) & 63;
                 ml &= ml - 1;
-                uint32_t x = 7u - (uint32_t)(b & 7), y = 7u - (uint32_t)(b >> 3);
+                uint32_t x = (uint32_t)(b & 7), y = (uint32_t)(b >> 3);
                 // zx*x + zy*y with x,y < 8 via 24-bit multiplies (FineRaster.inl:348 depth, U32 wrap).
                 uint32_t depth = d0 + __umul24(zxl, x) + (__umul24(zxh, x) << 24) + __umul24(zyl, y) + (__umul24(zyh, y) << 24);
                 bool live = true;
@@ -1056,14 +1120,14 @@ __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p
                     uint32_t pz = p.peel[((size_t)n * p.Hp + (Y0 + (int)y + p.vp.offy)) * p.Wp + (X0 + (int)x + p.vp.offx)];
                     live = depth > pz;                                               // FineRaster.inl:349
                 }
-                if (DBG && (p.dbg & 2048)) { if (depth == 0x12345u) keys[y * 8 + x] = depth; }            // experiment: the loop without its atomics
-                else if (live) atomicMin(&keys[y * 8 + x], ((unsigned long long)depth << 32) | idk);
+                if (DBG && (p.dbg & 2048)) { if (depth == 0x12345u) keys[b] = depth; }            // experiment: the loop without its atomics
+                else if (live) atomicMin(&keys[b], ((unsigned long long)depth << 32) | idk);      // (b = y * 8 + x)
             }
         }
     }
     const uint32_t m0lo = (uint32_t)m, m0hi = (uint32_t)(m >> 32);
     if (heavy && !(DBG && (p.dbg & 4096))) {
-        const uint32_t xl = 7u - (uint32_t)(lane & 7), yl = 7u - (uint32_t)(lane >> 3);       // this lane's pixel: bit `lane` of a mask
+        const uint32_t xl = (uint32_t)(lane & 7), yl = (uint32_t)(lane >> 3);                 // this lane's pixel: bit `lane` of a mask
         unsigned long long* keys0 = &sh.key[0][0][0];
         do {
             const int src = __builtin_ctzll(heavy);
@@ -1092,11 +1156,11 @@ __device__ __forceinline__ bool raster_pairs(FineShared& sh, const FineParams& p
                     const uint32_t pz = p.peel[((size_t)n * p.Hp + (sY0 + (int)yl + p.vp.offy)) * p.Wp + (sX0 + (int)xl + p.vp.offx)];
                     live = depth > pz;
                 }
-                if (live) atomicMin(&keys0[stile * 64 + (int)(yl * 8 + xl)], ((unsigned long long)depth << 32) | sidk);
+                if (live) atomicMin(&keys0[stile * 64 + lane], ((unsigned long long)depth << 32) | sidk);      // (lane = yl * 8 + xl)
             }
         } while (heavy);
     }
-    return kHot;
+    return kHot | kBig;
 }
 
 // One tile's depth bound for k_fine's per-tile depth cull, refreshed from the tile's keys: the largest depth any of its 64 pixels
@@ -1437,13 +1501,14 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     const int ky = (nx > 1) ? (int)(((float)k + 0.5f) / (float)nx) : k;   // exact for k < 64, nx <= 8
                     const int kx = k - ky * nx;
                     const int tx = x0 + kx - btx0, tyl = y0 + ky - bty0;
-                    const bool hotBatch = raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, act, (uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12),
-                                                                  btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
-                    // (kEarlyZTiles tiles per batch once covered tiles see more pairs; while nothing is there to cull, one tile
-                    // every NVDR_FINE_COLD batches: a scene without overdraw pays next to nothing)
+                    const int batch = raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, act, (uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12),
+                                                              btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
+                    // (kEarlyZTiles tiles per batch once covered tiles see more pairs; one after a batch with a large mask -- large
+                    // triangles are what covers tiles; otherwise one every NVDR_FINE_COLD batches: a mesh of small triangles without
+                    // overdraw pays next to nothing -- refreshing after every batch was 9 us of the headline's 145, r05a)
                     if (ezOn) {
-                        int nref = hotBatch ? kEarlyZTiles : 0;
-                        if (!hotBatch && ++cold >= NVDR_FINE_COLD) { cold = 0; nref = 1; }
+                        int nref = (batch & 1) ? kEarlyZTiles : (NVDR_FINE_ADAPT && (batch & 2)) ? 1 : 0;
+                        if (nref == 0 && ++cold >= NVDR_FINE_COLD) { cold = 0; nref = 1; }
 #pragma unroll 1
                         for (int rt = 0; rt < nref; rt++) {
                             refresh_tile_bound(sh, turn);
@@ -1477,7 +1542,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     qn += __popcll(m);
                     if (qn >= 64) {
                         __builtin_amdgcn_wave_barrier();
-                        const bool hotBatch = raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, true, sh.queue[wave][(head + lane) & (kQueueSize - 1)], btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
+                        const bool hotBatch = 1 & raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, true, sh.queue[wave][(head + lane) & (kQueueSize - 1)], btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
                         __builtin_amdgcn_wave_barrier();
                         head = (head + 64) & (kQueueSize - 1);
                         qn -= 64;
@@ -1537,7 +1602,9 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         // the shading launch: the merged keys, and the array back to all ones for the next call
 #pragma unroll
         for (int tt = 0; tt < kTilesPerWave; tt++) {
-            sh.key[tileRow][tile0 + tt][laneS] = gkeys[tt * 64];           // (read again below by this same lane)
+            // (the array rests at all ones; an untouched pixel takes the kernel's own sentinel, kInit, like the pixels of every
+            // other bin: the depth surface of a peeling pass then holds kDepthMax there, not 0xFFFFFFFF -- ADVICE r4)
+            sh.key[tileRow][tile0 + tt][laneS] = min(gkeys[tt * 64], kInit);           // (read again below by this same lane)
             gkeys[tt * 64] = ~0ull;
         }
     }
@@ -2010,7 +2077,8 @@ extern "C" int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const in
         // Bins with very many triangles are shared by several workgroups only when the launch cannot hide them: with
         // fewer bins than two rounds of resident workgroups the launch is as long as its heaviest bin (batch 16 at
         // 512^2: k_fine 91 -> 57 us); with more, the helpers' extra list building costs more than the shorter tail
-        // gains (batch 64: 126 -> 130 us).
+        // gains (batch 64: 126 -> 130 us in round 2; measured again in round 5 with thresholds of 768 ... 2000 triangles:
+        // 131 -> 133 ... 151 us -- the launch is bound by its throughput there, not by its longest workgroup).
         const bool dbgMode = debug_buffer() != nullptr || (debug_flags() & (4 | 8 | 16 | 128 | 256 | 512 | 2048 | 4096 | 8192)) != 0;
         const bool lists = L.listCap > 0 && !dbgMode;
         // (launches over large meshes always share: one bin may hold more triangles than all the others together)

@@ -373,10 +373,11 @@ class _TileRecord:
     __slots__ = ("flags", "ptr", "version", "shape", "kind", "__weakref__")
 
     def __init__(self, flags, t, kind):
-        self.flags, self.ptr, self.version, self.shape, self.kind = flags, t.data_ptr(), t._version, tuple(t.shape[:3]), kind
+        # (full shape AND strides: an alias of the same storage with another last dimension or layout does not inherit the record)
+        self.flags, self.ptr, self.version, self.shape, self.kind = flags, t.data_ptr(), t._version, (tuple(t.shape), t.stride()), kind
 
     def still(self, t):
-        return t.data_ptr() == self.ptr and t._version == self.version and tuple(t.shape[:3]) == self.shape
+        return t.data_ptr() == self.ptr and t._version == self.version and (tuple(t.shape), t.stride()) == self.shape
 
 
 def _attach_tiles(t, flags, kind):

@@ -130,7 +130,14 @@ class _LazyGrad(torch.Tensor):
                 _LazyGrad._zeros[key] = zero
         r = torch.Tensor._make_subclass(cls, zero.expand(like.shape), False)
         r._source, r._index = source, index
+        # An in-place operation on the stand-in (a hook doing g.mul_(2)) is carried out on the materialised values by
+        # __torch_dispatch__, below the level that counts versions -- the counter that moves is the STAND-IN's (shared by all
+        # stand-ins of this device and dtype: they are views of one zero).  unedited() compares it with what it was here.
+        r._v0 = r._version
         return r
+
+    def unedited(self):
+        return self._version == self._v0
 
     def materialize(self):
         return self._source.get()[self._index]
@@ -145,15 +152,24 @@ _LazyGrad._zeros = {}
 
 
 class _LazySource:
-    """Computes the real gradients behind one or two _LazyGrad objects, once, on first use; drops its inputs afterwards."""
-    __slots__ = ("thunk", "values")
+    """Computes the real gradients behind one or two _LazyGrad objects, once, on first use; drops its inputs afterwards.
+    `inputs` are the tensors the thunk reads: autograd's own saved-tensor check ran when the backward node unpacked them, so an
+    in-place change made AFTER that (an optimizer step between autograd.grad(loss, [rast]) and the first look at the result)
+    would go unnoticed -- their version counters are recorded here and compared at materialisation, with autograd's message."""
+    __slots__ = ("thunk", "values", "inputs")
 
-    def __init__(self, thunk):
+    def __init__(self, thunk, inputs=()):
         self.thunk, self.values = thunk, None
+        self.inputs = tuple((t, t._version) for t in inputs if t is not None)
 
     def get(self):
         if self.values is None:
-            self.values, self.thunk = self.thunk(), None
+            for t, version in self.inputs:
+                if t._version != version:
+                    raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                                       "a tensor read by the deferred gradient of rast is at version %d; expected version %d (the "
+                                       "gradient was requested before the change and first looked at after it)" % (t._version, version))
+            self.values, self.thunk, self.inputs = self.thunk(), None, ()
             _plugin.fused_backward_count("materialized")
         return self.values
 
@@ -257,7 +273,10 @@ class _RasterizeOp:
             # nobody added to it, no hook replaced it -- and what arrives for rast_db is nothing (plain interpolation),
             # irrelevant (grad_db=False) or interpolate's own g_rast_db
             db_ok = (d_rast_db is None and lz_db is None) or not grad_db or (lz_db is not None and d_rast_db is lz_db)
-            if d_rast is not None and d_rast is lz_rast and db_ok:
+            # ... and nobody has EDITED it on the way: a hook may have changed the gradient in place -- the object stays the same --
+            # so the prepared gradient stands only while the stand-in's version counter is where it was when it was made
+            untouched = lz_rast is not None and lz_rast.unedited() and (lz_db is None or lz_db.unedited())
+            if d_rast is not None and d_rast is lz_rast and db_ok and untouched:
                 _plugin.fused_backward_count("used")
                 return None, g_pos, None, None, None, None, None
             # rast's gradient has other contributors in this program: what was prepared is void, and preparing it again
@@ -318,7 +337,7 @@ class _InterpolateOp:
         if origin is not None and origin.usable_by(attr, rast, tri):
             g_attr, _, _, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, with_g_rast=False, tile_flags=flags)
             # g_rast itself is not written: autograd gets a stand-in that computes it if anybody looks (_LazyGrad)
-            source = _LazySource(lambda: (_plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)[1],))
+            source = _LazySource(lambda: (_plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)[1],), (attr, rast, tri, d_out))
             g_rast = _LazyGrad(rast, source, 0)
             origin.pending = (weakref.ref(g_rast), g_pos, None)
             return g_attr, g_rast
@@ -344,7 +363,7 @@ class _InterpolateOp:
                     attr, rast, tri, origin.pos, d_out, with_g_rast=False, tile_flags=flags, rast_db=rast_db, dda=d_out_da,
                     diff_attrs_all=diff_all, diff_attrs_vec=diff_list, db_to_pos=origin.grad_db)
                 source = _LazySource(lambda: _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
-                                                                         tile_flags=flags)[1:])
+                                                                         tile_flags=flags)[1:], (attr, rast, tri, d_out, rast_db, d_out_da))
                 g_rast, g_rast_db = _LazyGrad(rast, source, 0), _LazyGrad(rast_db, source, 1)
                 origin.pending = (weakref.ref(g_rast), g_pos, weakref.ref(g_rast_db))
                 return g_attr, g_rast, None, g_rast_db, None, None

@@ -197,6 +197,24 @@ def test_operator_layer_uses_the_fused_gradient_only_when_it_is_legal(dr, oracle
     within("hook on rast: g_rast seen", seen[0].cpu().numpy(), gr, grad_tol(gr))
     within("hook on rast: g_pos", pos_r.grad.cpu().numpy(), 2.0 * gp, grad_tol(2.0 * gp))
     _plugin.set_fused_backward("auto")                                                          # (the hook step made the context give up)
+    # (3d) ADVICE r4: a hook that edits the gradient IN PLACE leaves the stand-in object what it was -- the prepared position
+    # gradient must not be used then; and a deferred gradient first looked at after one of its inputs changed must raise
+    pos_r, attr_r, rast_r, loss = graph()
+    def edit_in_place(g):
+        g.mul_(2.0)                                                                              # (returns None: the object autograd carries on is the same stand-in)
+    rast_r.register_hook(edit_in_place)
+    before = _plugin.fused_backward_count()
+    loss.backward()
+    assert _plugin.fused_backward_count()["discarded"] == before["discarded"] + 1
+    within("in-place hook on rast: g_pos", pos_r.grad.cpu().numpy(), 2.0 * gp, grad_tol(2.0 * gp))
+    _plugin.set_fused_backward("auto")
+    pos_r, attr_r, rast_r, loss = graph()
+    (g_late,) = torch.autograd.grad(loss, [rast_r])
+    with torch.no_grad():
+        attr_r.add_(1.0)                                                                         # (an optimizer step)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        g_late.cpu()
+    _plugin.set_fused_backward("auto")
 
     # (4) another index buffer for the attributes: not this path's graph
     ctx2 = dr.RasterizeCudaContext()
