@@ -1071,6 +1071,282 @@ __global__ __launch_bounds__(256, 5) void k_tex_grad(const TexParams p, int grou
     }
 }
 
+// ---- the heavy blocks of the common case, leaner (round 5) -------------------------------------------------------------
+// k_tex_grad above is the general kernel: cube maps, every filter, any channel count -- 96 VGPRs with 20 B/lane of scratch, five
+// waves per SIMD, a third of its static code exec-mask bookkeeping (0.73 ms = 0.19 of the HBM peak on config 3's heavy blocks).
+// This one does the common case only -- 2-D texture, bilinear or trilinear filter with the level from uv_da, 1..4 channels, the
+// blocks the light kernel left over -- around the same LDS patch table, and is written for registers:
+//   * one mip level at a time (footprint, slots, four texels in flight, scatter, that level's share of the uv gradient) instead
+//     of both levels' eight texels and two footprints live together;
+//   * the level's adjoint with respect to uv_da is recomputed at the end from uv_da fetched again, so that neither lives across
+//     the taps;
+//   * pixels with IDENTICAL footprints (a constant-uv background inside a silhouette block) are found by comparing with the
+//     wave's first and last active lane and summed with DPP -- not by a segmented scan over all eight taps' coordinates; a wave
+//     that is one such group altogether leaves a record for k_tex_grad_fold like the light kernel's.
+// Round 5 also tried what the review asked for, a DENSE texel window per level instead of the table (cell = (y - y0) * W + x - x0,
+// no keys, no probes): 0.46 ms with the taps that fit, but on config 3's mesh -- jittered vertices, so the mip level changes from
+// triangle to triangle -- a 16x16-pixel block holds 4.7 distinct levels on average (up to 11), and with 34x34 texels for the
+// finest level, 18x18 and 10x10 for the next two, 45-64 % of the pixels had a tap outside (per-level corners and a 34x34 window
+// for EVERY level still lose 7-15 %, at 14 KB per level); those taps went to memory as scattered f32 atomics, 3.7 ms.  The
+// table adapts to where the taps are; a window does not (tools/exp_texwin_sim.py reproduces the count on the CPU).
+// Where this kernel's 0.71 ms go on config 3 (stages switched off one at a time, r05): 0.11 ms loads / level selection / stores,
+// 0.20 ms the eight 12-byte texel gathers and the uv gradient, 0.12 ms slot lookups and LDS adds, 0.27 ms the flush -- ~90 M
+// f32 atomics (every block writes each texel it touched once: ~700 texels x 3 channels x 40 k blocks) at the rate coalesced
+// runs of 24 lanes sustain.  What is left to gain is in the flush: larger blocks per table (fewer texels shared by neighbours).
+__device__ __forceinline__ uint32_t wave_min_u32_to_last(uint32_t v) {                 // result valid in lane 63
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xb1, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4e, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+template <int FILTER, int C>
+__global__ __launch_bounds__(256, 6) void k_tex_grad_lean(const TexParams p, int groups)
+{
+    constexpr bool kTri = (FILTER == TEX_LML);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    // LDS layout as in k_tex_grad: vals [groups*16*C] | keys [groups] | {block max, used count, -, -} | used-patch list [groups]
+    PatchTable tab{(uint32_t*)((int*)s_mem + (size_t)groups * 16 * C), (int*)s_mem, groups, C};
+    uint32_t* s_max = tab.keys + groups;
+    int* s_used = (int*)(s_max + 4);
+    int px = 0, py = 0, pz = 0, blk = 0; bool inside;
+    if (!tex_pixel(p, px, py, pz, inside, &blk)) return;
+    if (p.heavy && !p.heavy[blk]) return;                                    // finished by the light kernel
+    tab.clear(threadIdx.x, 256);
+    if (threadIdx.x == 0) { s_max[0] = 0u; s_max[1] = 0u; }
+    const int lane = threadIdx.x & 63;
+    const int tz = (p.texDepth == 1) ? 0 : pz;
+    const size_t pidx = (size_t)px + (size_t)p.imgW * (py + (size_t)p.imgH * pz);
+    const bool zt = inside && p.zflags.empty(pz, py, px);                    // uv = uv_da = 0 known for this tile: not read
+    float2 uv = make_float2(0.f, 0.f);
+    float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+    float d[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) d[c] = 0.f;
+    if (inside) {
+        const float* pDy = p.dy + pidx * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) d[c] = pDy[c];
+        if (!zt) {
+            uv = ((const float2*)p.uv)[pidx];
+            if (kTri) da = ((const float4*)p.uvDA)[pidx];
+        }
+    }
+    __syncthreads();
+    // ---- phase A: zero stores for pixels without an upstream gradient (:922-971); the block's largest |dy| ---------------
+    bool active = false;
+    float m = 0.f;
+    {
+        uint32_t dmax = 0u;
+#pragma unroll
+        for (int c = 0; c < C; c++) { dmax |= (uint32_t)__float_as_int(d[c]); m = max_abs_keep_nan(m, d[c]); }
+        active = inside && !(__int_as_float((int)dmax) == 0.f);
+        if (inside && !active) {
+            ((float2*)p.gradUV)[pidx] = make_float2(0.f, 0.f);
+            if (kTri) {
+                if (p.gradUVDA) ((float4*)p.gradUVDA)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.gradBias) p.gradBias[pidx] = 0.f;
+            }
+        }
+        if (!active) m = 0.f;
+    }
+    block_max_update(s_max, m);
+    int level0 = 0, level1 = 0; float flevel = 0.f;
+    if (kTri && active) tex_mip_level<FILTER, false, false>(p, pidx, level0, level1, flevel, nullptr, make_float3(0.f, 0.f, 0.f), nullptr, zt, &da);
+    __syncthreads();
+    const uint32_t maxBits = s_max[0];
+    if (maxBits == 0u) return;                                   // nobody has anything to scatter
+    const bool direct = maxBits >= 0x7F800000u;                  // inf or NaN present: plain f32 atomics
+    const FixedScale32 fs(direct ? 0x3F800000u : maxBits);
+
+    // ---- identical footprints inside the wave ------------------------------------------------------------------------------
+    // dsc[c] = what this lane scatters for channel c: its own upstream gradient; the group's total for a group's first lane;
+    // nothing for the group's other lanes.
+    const uint64_t act = __ballot(active);
+    float dsc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) dsc[c] = d[c];
+    bool scatters = active;
+    bool uniformWave = false;
+    {
+        const float bias = (kTri && p.bias && inside) ? p.bias[pidx] : 0.f;
+        auto group = [&](int leader, uint64_t& members) {
+            bool same = active;
+            same &= __float_as_int(uv.x) == __builtin_amdgcn_readlane(__float_as_int(uv.x), leader);
+            same &= __float_as_int(uv.y) == __builtin_amdgcn_readlane(__float_as_int(uv.y), leader);
+            if (kTri) {
+                same &= __float_as_int(da.x) == __builtin_amdgcn_readlane(__float_as_int(da.x), leader);
+                same &= __float_as_int(da.y) == __builtin_amdgcn_readlane(__float_as_int(da.y), leader);
+                same &= __float_as_int(da.z) == __builtin_amdgcn_readlane(__float_as_int(da.z), leader);
+                same &= __float_as_int(da.w) == __builtin_amdgcn_readlane(__float_as_int(da.w), leader);
+                if (p.bias) same &= __float_as_int(bias) == __builtin_amdgcn_readlane(__float_as_int(bias), leader);
+            }
+            members = __ballot(same);
+            if (__popcll(members) > 1) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float tot = wave_sum_to_last(same ? d[c] : 0.f);
+                    const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
+                    if (lane == leader) dsc[c] = t;
+                }
+                if (same && lane != leader) scatters = false;
+            }
+        };
+        uint64_t mA = 0ull, mB = 0ull;
+        if (act) {
+            group(__builtin_ctzll(act), mA);
+            const uint64_t rest = act & ~mA;
+            if (rest) group(63 - __builtin_clzll(rest), mB);
+            // a wave that is ONE group of pixels without a footprint: level 0, one quad -- a record for k_tex_grad_fold (a background
+            // sends one total per wave to the same four texels from thousands of blocks: same-address f32 atomics execute one by one)
+            if (mA == ~0ull && p.rec) {
+                bool flat = !kTri || (da.x == 0.f && da.y == 0.f && da.z == 0.f && da.w == 0.f && !(fabsf(bias) == INFINITY));
+                uniformWave = __ballot(flat) == ~0ull;
+            }
+        }
+    }
+
+    if (active) {
+        const float* const* texp = p.tex;
+        float gu = 0.f, gv = 0.f, s0 = 0.f, s1 = 0.f;
+        const bool second = kTri && flevel > 0.f;
+#pragma unroll
+        for (int l = 0; l < (kTri ? 2 : 1); l++) {
+            if (l == 1 && !second) break;
+            const int level = l == 0 ? level0 : level1;
+            const Quad q = tex_index_linear(p, uv.x, uv.y, tz, level);
+            const float w11 = q.fu * q.fv, w10 = q.fu - w11, w01 = q.fv - w11, w00 = 1.f - q.fu - w01;
+            const float tw[4] = {w00, w10, w01, w11};
+            const float* pIn = texp[level];
+            float ta[4][C];
+#pragma unroll
+            for (int k = 0; k < 4; k++) load_texel<C>(ta[k], pIn, q.tc[k], C);
+            // table slots of the four taps (-1: to memory): the taps of a footprint share patches most of the time
+            int cell[4] = {-1, -1, -1, -1};
+            int lost = 0;                                        // sign bit: some valid tap of this lane has no slot
+            if (scatters && !direct && !uniformWave) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (q.tc[k] < 0) continue;
+                    bool reused = false;
+#pragma unroll
+                    for (int j = 0; j < k; j++) {
+                        if (!reused && q.tc[j] >= 0 && cell[j] >= 0 && (q.tx[k] >> 3) == (q.tx[j] >> 3) && (q.ty[k] >> 1) == (q.ty[j] >> 1)) {
+                            cell[k] = (cell[j] & ~15) + (q.ty[k] & 1) * 8 + (q.tx[k] & 7);
+                            reused = true;
+                        }
+                    }
+                    if (!reused) cell[k] = tab.find(level, q.tx[k], q.ty[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) lost |= (~q.tc[k] & cell[k]);
+            const float lw = !kTri ? 1.f : l == 0 ? 1.f - flevel : flevel;       // this level's share
+            const bool anyLost = !uniformWave && __ballot(scatters && lost < 0) != 0ull;
+            if (scatters && !uniformWave) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const float dl = dsc[c] * lw;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (cell[k] >= 0) atomicAdd(&tab.vals[cell[k] * C + c], fs.to_fixed(tw[k] * dl));
+                }
+            }
+            if (anyLost && scatters) {
+                float* g = p.gradTex[level];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (q.tc[k] >= 0 && cell[k] < 0) {
+#pragma unroll
+                        for (int c = 0; c < C; c++) atomic_add_f32(g + q.tc[k] * C + c, tw[k] * (dsc[c] * lw));
+                    }
+            }
+            // uv gradient of this level (texture_kernel.cu:1046-1094), with the pixel's OWN upstream gradient
+            const float sclu = (float)level_dim(p.texW, level), sclv = (float)level_dim(p.texH, level);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float a0 = ta[0][c], a1 = ta[1][c], a2 = ta[2][c], a3 = ta[3][c];
+                const float ad = (a3 + a0 - a1 - a2);
+                const float dl = kTri ? (l == 0 ? (1.f - flevel) * d[c] : flevel * d[c]) : d[c];
+                gu += dl * ((a1 - a0) + q.fv * ad) * sclu;
+                gv += dl * ((a2 - a0) + q.fu * ad) * sclv;
+                if (kTri) { const float b = bilerp1(a0, a1, a2, a3, q.fu, q.fv) * d[c]; if (l == 0) s0 += b; else s1 += b; }
+            }
+        }
+        ((float2*)p.gradUV)[pidx] = make_float2(gu, gv);
+        if (kTri) {
+            const float df = second ? s1 - s0 : 0.f;
+            if (p.gradBias) p.gradBias[pidx] = df;
+            if (p.gradUVDA) {
+                float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+                int l0, l1; float fl;
+                const float4 da2 = zt ? make_float4(0.f, 0.f, 0.f, 0.f) : ((const float4*)p.uvDA)[pidx];
+                tex_mip_level<FILTER, false, false>(p, pidx, l0, l1, fl, &dw, make_float3(0.f, 0.f, 0.f), nullptr, zt, &da2);
+                ((float4*)p.gradUVDA)[pidx] = make_float4(dw.x * df, dw.y * df, dw.z * df, dw.w * df);
+            }
+        }
+    }
+    if (uniformWave) {
+        // one record for the wave (the totals are with the group's first lane, lane 0)
+        const Quad q0 = tex_index_linear(p, uv.x, uv.y, tz, 0);
+        const float w011 = q0.fu * q0.fv, w010 = q0.fu - w011, w001 = q0.fv - w011, w000 = 1.f - q0.fu - w001;
+        const float tw0[4] = {w000, w010, w001, w011};
+        int* recBase = p.rec + (blk * 4 + (int)(threadIdx.x >> 6));
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int tot = __builtin_amdgcn_readfirstlane(__float_as_int(dsc[c]));
+            if (lane == 63) recBase[(size_t)(kTexRecHeader + c) * p.nrec] = tot;
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                recBase[(size_t)(4 + k) * p.nrec] = __float_as_int(tw0[k]);
+                if (k > 0) recBase[(size_t)k * p.nrec] = q0.tc[k];
+            }
+            // tap 0's index makes the record valid; a record whose FIRST tap has no texel carries the first valid tap in front
+            int first = q0.tc[0];
+            if (first < 0) {
+#pragma unroll
+                for (int k = 1; k < 4; k++) {
+                    if (first < 0 && q0.tc[k] >= 0) {
+                        first = q0.tc[k];
+                        recBase[(size_t)4 * p.nrec] = __float_as_int(tw0[k]);
+                        recBase[(size_t)k * p.nrec] = -1;
+                    }
+                }
+            }
+            recBase[0] = first;
+        }
+    }
+    if (direct) return;
+
+    // ---- flush: consecutive lanes take consecutive (texel, channel) entries of a patch row (as k_tex_grad) -----------------
+    __syncthreads();
+    for (int g = threadIdx.x; g < groups; g += 256)
+        if (tab.keys[g] != 0u) s_used[atomicAdd(&s_max[1], 1u)] = g;
+    __syncthreads();
+    constexpr int perGroup = 16 * C;
+    const int n = (int)s_max[1] * perGroup;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int u = i / perGroup;
+        const int g = s_used[u];
+        const uint32_t key = tab.keys[g];
+        const int r = i - u * perGroup;
+        const int t = tab.vals[g * perGroup + r];
+        if (t == 0) continue;
+        const int tx = r / C, c = r - tx * C;
+        const int level = (int)(key >> 27) - 1;
+        const int x = (int)(key & 0xFFFu) * 8 + (tx & 7);
+        const int y = (int)((key >> 12) & 0x7FFFu) * 2 + (tx >> 3);
+        const int w = level_dim(p.texW, level), h = level_dim(p.texH, level);
+        if (x >= w || y >= h) continue;                          // cannot happen: only valid texels are inserted
+        atomic_add_f32(p.gradTex[level] + ((tz * h + y) * w + x) * C + c, fs.to_float(t));
+    }
+}
+
 // First kernel of the two-kernel gradient pass (2-D textures, bilinear footprints, caller scratch): everything that needs no
 // scatter machinery, at the occupancy of a streaming kernel.  k_tex_grad carries 96 VGPRs and a 26 KB table for its general
 // path, so five waves per SIMD is all a background pixel gets there -- and three quarters of a rendered image's pixels are
@@ -1996,7 +2272,21 @@ extern "C" int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs_
             NVDR_LAUNCH_CHECK();
         }
     }
-    {
+    // the heavy blocks through the lean kernel where it applies (2-D, level from uv_da, bilinear footprints, 1..4 channels,
+    // two-kernel pass, a table), else through the general one
+    const bool lean = p.heavy && groups > 0 && !cube && !bo && (filter_mode == TEX_LINEAR || filter_mode == TEX_LML) && C >= 1 && C <= 4
+                      && tune_int("NVDR_TUNE_TEX_LEAN", 1);
+    if (lean) {
+        ProfileScope ps("tex_grad", stream);
+#define NVDR_TEX_LEAN(FILTER)                                                                                        \
+    do {                                                                                                             \
+        if (C == 1)      hipLaunchKernelGGL((k_tex_grad_lean<FILTER, 1>), grid, dim3(256), lds, stream, p, groups);  \
+        else if (C == 2) hipLaunchKernelGGL((k_tex_grad_lean<FILTER, 2>), grid, dim3(256), lds, stream, p, groups);  \
+        else if (C == 3) hipLaunchKernelGGL((k_tex_grad_lean<FILTER, 3>), grid, dim3(256), lds, stream, p, groups);  \
+        else             hipLaunchKernelGGL((k_tex_grad_lean<FILTER, 4>), grid, dim3(256), lds, stream, p, groups);  \
+    } while (0)
+        if (filter_mode == TEX_LINEAR) NVDR_TEX_LEAN(TEX_LINEAR); else NVDR_TEX_LEAN(TEX_LML);
+    } else {
         ProfileScope ps("tex_grad", stream);
 #define NVDR_TEX_GRAD_C(FILTER, BO, CUBE, CC) hipLaunchKernelGGL((k_tex_grad<FILTER, BO, CUBE, CC>), grid, dim3(256), lds, stream, p, groups)
 #define NVDR_TEX_GRAD(FILTER, BO)                                                                              \

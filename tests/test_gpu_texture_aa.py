@@ -389,4 +389,7 @@ def test_texture_backward_two_level_reduction_of_constant_regions(dr, oracle, bm
     finally:
         _plugin._TEX_GRAD_SCRATCH = True
     within("one-level tex grad: g_tex", one[0], g["tex"], _tol(g["tex"]))
-    assert np.array_equal(one[1], got[1]) and np.array_equal(one[2], got[2])
+    # (the two paths run different kernels since round 5 -- the dense-window kernel sums a pixel's uv gradient level by level, the
+    # general one channel by channel -- so their pixel gradients agree to rounding, not bit for bit)
+    within("one-level tex grad: g_uv", one[1], g["uv"], _tol(g["uv"]))
+    within("one-level tex grad: g_uv_da", one[2], g["uv_da"], _tol(g["uv_da"]))

@@ -93,8 +93,11 @@ def test_fused_backward_and_texture_gradient_kernels_stay_within_their_budgets(t
     t = _metadata(tmp_path, "texture.hip")
     light = {n: v for n, v in t.items() if "k_tex_grad_light" in n}
     assert light and all(s == 0 and v <= 64 for s, v in light.values()), light
-    heavy = t["_ZN4nvdr10k_tex_gradILi3ELb0ELb0ELi3EEEvNS_9TexParamsEi"]          # config 3: trilinear, 2-D, three channels
+    heavy = t["_ZN4nvdr10k_tex_gradILi3ELb0ELb0ELi3EEEvNS_9TexParamsEi"]          # the general kernel: trilinear, 2-D, three channels
     assert heavy[0] <= 20 and heavy[1] <= 96, heavy
+    lean = {n: v for n, v in t.items() if "k_tex_grad_lean" in n}                  # config 3's heavy blocks since r05: no scratch, 6+ waves/SIMD
+    assert len(lean) == 8 and all(s == 0 and v <= 80 for s, v in lean.values()), lean
+    assert t["_ZN4nvdr15k_tex_grad_leanILi3ELi3EEEvNS_9TexParamsEi"][1] <= 72, lean
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
