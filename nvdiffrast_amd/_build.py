@@ -66,9 +66,30 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_ffi(force=force, verbose=verbose)
     return LIB_PATH
 
 
+FFI_SRC = os.path.join(_HERE, "csrc_host", "nvdr_ffi.c")
+FFI_PATH = os.path.join(_HERE, "_nvdr_ffi.so")
+
+
+def build_ffi(force=False, verbose=False):
+    """The compiled call layer between Python and the C ABI (csrc_host/nvdr_ffi.c): plain C against the CPython headers, gcc."""
+    if not force and os.path.exists(FFI_PATH) and os.path.getmtime(FFI_PATH) > os.path.getmtime(FFI_SRC):
+        return FFI_PATH
+    import sysconfig
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("gcc not found; cannot build _nvdr_ffi.so (the package falls back to ctypes without it)")
+    cmd = [cc, "-O2", "-Wall", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], FFI_SRC, "-o", FFI_PATH]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return FFI_PATH
+
+
 if __name__ == "__main__":
+    build_ffi(force=True, verbose=True)
     build(force=True, verbose=True)
     print(LIB_PATH)

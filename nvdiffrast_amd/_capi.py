@@ -98,8 +98,45 @@ def load():
     if lib.nvdr_abi_version() != ABI_VERSION:
         raise RuntimeError(f"nvdiffrast_amd: {path} has ABI version {lib.nvdr_abi_version()}, this package needs "
                            f"{ABI_VERSION}; rebuild it with `python -m nvdiffrast_amd._build`.")
-    _lib = lib
-    return lib
+    _lib = _compiled_binding(lib)
+    return _lib
+
+
+class _BoundLib:
+    """The library's entry points behind the compiled call layer (csrc_host/nvdr_ffi.c): every name of SIGNATURES whose
+    parameters are plain pointers and integers is a `_nvdr_ffi.bind` callable (same arguments as the ctypes function: ints,
+    None for NULL, ctypes arrays for host arrays); anything else -- `nvdr_last_error`, symbols outside the table -- is the
+    ctypes function.  `ffi` tells which layer is in use."""
+
+    def __init__(self, cdll, bound):
+        self.__dict__["_cdll"] = cdll
+        self.__dict__["ffi"] = bool(bound)
+        self.__dict__.update(bound)
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["_cdll"], name)
+
+
+def _compiled_binding(cdll):
+    """ctypes spends 1.5-5 us per call converting twenty arguments; the compiled layer 0.15 us (the reference's pybind11 module,
+    csrc/torch/torch_bindings.cpp:43-71, is compiled too).  NVDR_FFI=0, or a module that has not been built: plain ctypes."""
+    if os.environ.get("NVDR_FFI", "1") in ("0", ""):
+        return _BoundLib(cdll, {})
+    try:
+        from . import _nvdr_ffi
+    except ImportError:
+        return _BoundLib(cdll, {})
+    # (host arrays -- the diff-attribute list, the mip pointer arrays -- arrive as ctypes arrays: buffers; entry points that take
+    # ctypes.byref() objects, nvdr_texture_mip_info and nvdr_profile_read, stay with ctypes: neither is on a hot path)
+    code = {c_void_p: "p", c_int: "i", c_size_t: "n", c_longlong: "L", _i32p: "p", _vpp: "p", ctypes.c_char_p: "p"}
+    res = {c_int: "i", c_size_t: "n", None: "v"}
+    bound = {}
+    for name, (restype, argtypes) in SIGNATURES.items():
+        if restype not in res or any(a not in code for a in argtypes) or len(argtypes) > 28:
+            continue
+        addr = ctypes.cast(getattr(cdll, name), c_void_p).value
+        bound[name] = _nvdr_ffi.bind(addr, res[restype] + "".join(code[a] for a in argtypes))
+    return _BoundLib(cdll, bound)
 
 
 def check(rc, what):

@@ -307,3 +307,39 @@ def test_scratch_sizes_of_the_two_policies():
     assert st.pool_hint(2, 100) == 600                                   # small meshes: the complete worst case
     assert st.grow_pool(N, T, 400000) == 501024 and st.pool_hint(N, T) == 501024
     assert lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB) == 1024
+
+
+def test_compiled_call_layer_binds_the_table_and_agrees_with_ctypes():
+    """csrc_host/nvdr_ffi.c: the compiled binding between Python and the C ABI (the reference's is pybind11,
+    torch_bindings.cpp:43-71).  Every entry point of the table whose parameters are plain pointers and integers is bound
+    through it, it converts None / ints / host arrays like ctypes does, rejects what does not fit, and NVDR_FFI=0 gives the
+    plain ctypes library (the fallback when the module has not been built)."""
+    import ctypes
+    import subprocess
+    import sys
+    from nvdiffrast_amd import _capi, _nvdr_ffi
+    lib = _capi.load()
+    assert lib.ffi, "the compiled call layer was not built (python -m nvdiffrast_amd._build)"
+    hot = ("nvdr_rasterize_fwd", "nvdr_rasterize_grad", "nvdr_interpolate_fwd", "nvdr_interpolate_grad", "nvdr_interpolate_rasterize_grad",
+           "nvdr_texture_fwd", "nvdr_texture_grad", "nvdr_antialias_fwd", "nvdr_antialias_grad")
+    for name in hot:
+        assert type(getattr(lib, name)).__name__ == "BoundFn", name
+    # same results as ctypes on calls that need no GPU
+    cd = lib._cdll
+    assert lib.nvdr_rasterize_scratch_bytes(4, 100, 64, 64) == cd.nvdr_rasterize_scratch_bytes(4, 100, 64, 64) > 0
+    assert lib.nvdr_tile_flags_bytes(64, 512, 512) == cd.nvdr_tile_flags_bytes(64, 512, 512)
+    assert lib.nvdr_rasterize_scratch_bytes_pool(2, 50000, 128, 128, 1234) == cd.nvdr_rasterize_scratch_bytes_pool(2, 50000, 128, 128, 1234)
+    arr = (ctypes.c_int32 * 3)(0, 1, 2)                              # a host array by object
+    assert lib.nvdr_interpolate_fwd(None, None, None, None, 0, 1, 1, 1, 1, 8, 8, 4, 0, arr, 3, None, None, None, None) != 0
+    assert b"null pointer" in lib.nvdr_last_error()
+    with pytest.raises(TypeError):
+        lib.nvdr_rasterize_scratch_bytes(4, 100, 64)                 # arity
+    with pytest.raises(TypeError):
+        lib.nvdr_rasterize_scratch_bytes(4, None, 64, 64)            # None for an int
+    with pytest.raises(OverflowError):
+        lib.nvdr_rasterize_scratch_bytes(1 << 40, 100, 64, 64)       # does not fit an int
+    with pytest.raises(ValueError):
+        _nvdr_ffi.bind(0, "x")
+    r = subprocess.run([sys.executable, "-c", "from nvdiffrast_amd import _capi; l = _capi.load(); print(l.ffi, l.nvdr_abi_version())"],
+                       capture_output=True, text=True, env=dict(os.environ, NVDR_FFI="0"), cwd=ROOT)
+    assert r.stdout.split() == ["False", str(_capi.ABI_VERSION)], r.stdout + r.stderr
