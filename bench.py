@@ -529,7 +529,8 @@ class Job:
             big = self.scene_name.startswith("t1m")
             if big:                                   # a million triangles: the reference under its CPU shim takes minutes; the C oracle, pinned to it by the tests, seconds
                 chk, chk_name = oracle, "oracle"
-            ns = 1 if big else min(2, self.N)
+            # (the reference under its CPU shim renders ~1.9 Mpix/s: eight items of the benchmark mesh are a few seconds)
+            ns = 1 if big else min(8 if self.scene_name == "m10k" else 2, self.N)
             ro, _ = chk.rasterize(sc["pos"][:ns], sc["tri"], (RES, RES))
             Gs = self.G[:ns].cpu().numpy()
             ga_o, gr_o, _ = chk.interpolate_grad(sc["attr"], ro, sc["tri"], Gs)
@@ -562,8 +563,9 @@ class Job:
         # four-op chain, one item at the config's own resolution and texture size: every op against the reference ON THE INPUTS
         # THE HIP PATH GAVE IT (oracle/chain.py explains why a chain through a texture is not judged end to end)
         from oracle.chain import four_op_chain
-        res = four_op_chain(dr, self.ctx, self.topo, chk, sc["pos"][:1], sc["tri"], sc["uv"], self.tex_np, self.G[:1], (RES, RES), dev=dev)
-        res.update({"against": chk_name, "items": 1, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]), "bar": PARITY_BAR,
+        nc = min(2, self.N)
+        res = four_op_chain(dr, self.ctx, self.topo, chk, sc["pos"][:nc], sc["tri"], sc["uv"], self.tex_np, self.G[:nc], (RES, RES), dev=dev)
+        res.update({"against": chk_name, "items": nc, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]), "bar": PARITY_BAR,
                     "compared": "each op on identical inputs (the HIP path's own intermediate tensors)"})
         return res
 
@@ -656,7 +658,7 @@ def graph_replay_in_child(argv, keys, script=None):
 def extra_config(name, dev, steps, warmup, windows, with_cpu, graph_too=False):
     """One more BASELINE config measured in this process (single GPU): the block that goes under `configs`."""
     wl = WORKLOADS[name]
-    N = wl["per_gpu"]
+    N = wl["per_gpu"] or wl["total"]                    # (c4: configs[3]'s 256 items on ONE GPU, the N = 1 point of its strong-scaling curve)
     job = Job(name, N, N, 0, 0, 1, dev, False, wl["res"], False, 1, False)
     host, evt = job.timed_windows(job.step, warmup, steps, windows)
     ms, timing = window_stats(host, evt, steps)
@@ -881,7 +883,7 @@ def main():
             del job
             torch.cuda.empty_cache()
             configs = {}
-            for name, st in (("c2", 20), ("c3", 6), ("dense", 10), ("s10k", 6), ("t1m", 6), ("t1m_shuffled", 6)):
+            for name, st in (("c2", 20), ("c3", 6), ("c4", 6), ("dense", 10), ("s10k", 6), ("t1m", 6), ("t1m_shuffled", 6)):
                 try:
                     configs[name] = extra_config(name, dev, st, 3, 5 if name in ("c2", "c3") else 3,
                                                  with_cpu=(name == "c3" and not args.no_cpu_baseline), graph_too=(name == "c2"))

@@ -63,7 +63,12 @@ def test_default_run_carries_the_other_baseline_configs():
     assert j["config"]["batch_per_gpu"] == 64 and j["parity"]["tri_id_mismatches"] == 0
     assert j["parity"]["all_items"]["items"] == 64 and j["parity"]["all_items"]["tri_id_mismatches"] == 0
     cf = j["configs"]
-    assert set(cf) == {"c2", "c3", "c5_standin", "dense", "s10k", "t1m", "t1m_shuffled"} == set(ln["configs"])
+    assert set(cf) == {"c2", "c3", "c4", "c5_standin", "dense", "s10k", "t1m", "t1m_shuffled"} == set(ln["configs"])
+    # configs[3] on ONE GPU: the N = 1 point of its strong-scaling curve, ids against the reference itself
+    c4 = cf["c4"]
+    assert "error" not in c4, c4
+    assert c4["batch"] == 256 and c4["ms_per_step"] > 0 and c4["parity"]["tri_id_mismatches"] == 0 and c4["parity"]["items"] == 8
+    assert j["parity"]["items"] == 8 and cf["c3"]["parity"]["items"] == 2          # full-size items against oracle/_ref (r04: 2 and 1)
     for name in ("dense", "s10k", "t1m", "t1m_shuffled"):            # the regimes the benchmark scene hides
         c = cf[name]
         assert "error" not in c, c
