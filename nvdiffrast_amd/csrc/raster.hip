@@ -908,7 +908,9 @@ struct FineParams {
 
 
 constexpr int kEarlyZTiles = 4;                          // tile bounds a wave refreshes per batch of 64 pairs once covered tiles see more pairs (k_fine)
+#if !NVDR_FINE_DIRECT
 constexpr int kQueueSize = 128;
+#endif
 
 // Build-time variants of k_fine's pair stage (tools/build_variant.sh passes -D flags for A/B runs on one GPU box):
 //   NVDR_FINE_DIRECT   1: a wave's 64 pairs go from the lanes that numbered them straight into raster_pairs (registers);
@@ -933,6 +935,9 @@ constexpr int kQueueSize = 128;
 #endif
 #ifndef NVDR_FINE_PK16
 #define NVDR_FINE_PK16 1
+#endif
+#ifndef NVDR_FINE_CLEAR_ROWS
+#define NVDR_FINE_CLEAR_ROWS 1
 #endif
 #ifndef NVDR_FINE_COLD
 #define NVDR_FINE_COLD 8
@@ -1242,6 +1247,24 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         int lane;                                              // taken afresh (opaque): nothing of this stays live across the raster stage
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         const int n2 = packed >> 10, by2 = (packed >> 5) & 31, bx2 = packed & 31;
+#if NVDR_FINE_CLEAR_ROWS
+        // a wave's eight pixel rows of the bin, ONE ROW PER STORE: 64 lanes x 16 B = 1 KiB contiguous (tile by tile a store was
+        // eight 128-byte pieces 8 KB apart)
+        const int X = bx2 * kBinTiles * 8 + lane;
+        const int Y0 = (by2 * kBinTiles + wave / kWavesPerRow) * 8;
+        if (Y0 >= q.vp.vph) return;
+        if (X < q.vp.vpw) {
+#pragma unroll 1
+            for (int r = 0; r < 8; r++) {
+                if (Y0 + r >= q.vp.vph) break;
+                const size_t pidx = ((size_t)n2 * q.H + (Y0 + r + q.vp.offy)) * q.W + (X + q.vp.offx);
+                ((float4*)q.out)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                store_streaming((float4*)q.out_db + pidx, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+        if (q.tileFlags && lane < kBinTiles && (bx2 * kBinTiles + lane) * 8 < q.vp.vpw)        // lane t: the row's tile t
+            q.tileFlags[((size_t)n2 * q.tfH + ((Y0 + q.vp.offy) >> 3)) * q.tfW + (((bx2 * kBinTiles + lane) * 8 + q.vp.offx) >> 3)] = 0;
+#else
         const int Y = (by2 * kBinTiles + wave / kWavesPerRow) * 8 + (lane >> 3);
         if (Y >= q.vp.vph) return;
 #pragma unroll 1
@@ -1254,6 +1277,7 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (q.tileFlags && lane == 0)                      // (lane 0 = the tile's first pixel: inside the viewport here)
                 q.tileFlags[((size_t)n2 * q.tfH + ((Y + q.vp.offy) >> 3)) * q.tfW + ((X + q.vp.offx) >> 3)] = 0;
         }
+#endif
         if (q.rowCov && lane == 0) q.rowCov[((size_t)(n2 * q.binsY + by2) * q.binsX + bx2) * kBinTiles + wave / kWavesPerRow] = 0;
     };
     // Empty bins are pure stores, and in the heavy-first order they all come last: 300 MB of zeros at the headline batch
@@ -1579,7 +1603,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
     // shader's per-lane constants were computed up front and parked in scratch across the raster stage.
     int laneS;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(laneS));
-    const int lx = laneS & 7, ly = laneS >> 3;
     const int tileRow = wave / kWavesPerRow, tile0 = (wave % kWavesPerRow) * kTilesPerWave;
     // ---- a bin shared by several workgroups: every part publishes its key array in memory and counts itself in; the
     //      part that arrives last takes the minimum over all parts (the same order-free rule as in LDS) and shades the
@@ -1633,23 +1656,30 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         __syncthreads();
         if (!sh.count) return;
     }
-    // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w -----------
+    // ---- pixel shader (rasterize.cu:15-114) + stores: wave w shades tile row w, ONE PIXEL ROW PER ITERATION ----------------
+    // lane l = pixel column l of the bin: a store instruction then writes 64 x 16 B = 1 KiB of one image row in one piece.  Shaded tile
+    // by tile (lane = pixel of an 8x8 tile) every store was eight 128-byte pieces, 8 KB apart -- same bytes, but the memory side
+    // takes whole kilobytes faster: the empty bins' zeros written row by row took the launch from 138 to 129 us (r05i), and four
+    // fifths of this kernel's stores are zeros of empty tiles.  The keys of a row sit in eight tiles' arrays (an 8-way bank
+    // conflict on eight LDS reads per wave: noise next to the stores).
+    static_assert(kWavesPerRow == 1 && kTilesPerWave == 8, "the shader walks a whole tile row per wave");
     const int ty = bty0 + tileRow;
-    const int Y = ty * 8 + ly;                  // viewport-local pixel row
+    const int X = btx0 * 8 + laneS;             // viewport-local pixel column
     const float4* vb = (const float4*)p.pos + (p.instance ? (size_t)n * p.V : 0);
-    uint64_t rowAny = 0ull;
+    const int kcol = (laneS >> 3) * 64 + (laneS & 7);            // this column in its tile's key array (+ 8 * pixel row)
+    uint64_t rowAny = 0ull;                     // bit l: column l shows a triangle in some row of this tile row
 #pragma unroll 1
-    for (int tt = 0; tt < kTilesPerWave; tt++) {
-        const int t = tile0 + tt;
-        const int X = (btx0 + t) * 8 + lx;
-        unsigned long long key = sh.key[tileRow][t][laneS];
+    for (int r = 0; r < 8; r++) {
+        const int Y = ty * 8 + r;               // viewport-local pixel row
+        unsigned long long key = (&sh.key[tileRow][0][0])[kcol + r * 8];
         if (!LIST && SPLIT && parts > 1) {                                       // (the last part only)
             // the other parts' keys: agent-scope atomic LOADS -- they observe the parts' exchanges wherever those ran, like the
             // returning atomics this loop used before, but several of them are in flight at a time (a bin shared by 64 parts reads
             // 512 values per lane here: one dependent round trip each was the launch's critical path)
+            const unsigned long long* gk = gkeys - laneS + kcol + r * 8;           // (gkeys: the tile row's first array, + lane)
 #pragma unroll 4
             for (int q = 0; q < parts; q++) {
-                const unsigned long long other = __hip_atomic_load(&gkeys[(q == part ? part : q) * 4096 + tt * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long other = __hip_atomic_load(&gk[(q == part ? part : q) * 4096], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 key = min(key, q == part ? key : other);
             }
         }
@@ -1657,15 +1687,9 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             if (X < vpwPad && Y < vphPad)
                 p.depth[((size_t)n * p.Hp + (Y + p.vp.offy)) * p.Wp + (X + p.vp.offx)] = (uint32_t)(key >> 32);
         }
-        if (p.tileFlags) {
-            // tile occupancy for the consumers of rast (TileFlags): does any pixel of this tile, inside the viewport, show a triangle?
-            const bool hit = (X < p.vp.vpw) & (Y < p.vp.vph) & ((uint32_t)key != 0xFFFFFFFFu);
-            const uint64_t any = __ballot(hit);
-            rowAny |= any;
-            if (laneS == 0 && X < p.vp.vpw && Y < p.vp.vph)    // lane 0 = the tile's first pixel
-                p.tileFlags[((size_t)n * p.tfH + ((Y + p.vp.offy) >> 3)) * p.tfW + ((X + p.vp.offx) >> 3)] = any ? 1 : 0;
-        }
-        if (X >= p.vp.vpw || Y >= p.vp.vph) continue;
+        const bool inImage = (X < p.vp.vpw) & (Y < p.vp.vph);
+        rowAny |= __ballot(inImage & ((uint32_t)key != 0xFFFFFFFFu));
+        if (!inImage) continue;
         const int px = X + p.vp.offx, py = Y + p.vp.offy;
         const size_t pidx = ((size_t)n * p.H + py) * p.W + px;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f), odb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1719,6 +1743,13 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             // keeps it from displacing `rast` (re-read by the next three kernels) in the Infinity Cache.
             store_streaming((float4*)p.out_db + pidx, odb);
         }
+    }
+    if (p.tileFlags && laneS < kBinTiles) {
+        // tile occupancy for the consumers of rast (TileFlags): lane t stores the flag of the row's tile t -- does any of its pixels,
+        // inside the viewport, show a triangle?
+        const int Xt = (btx0 + laneS) * 8, Yt = ty * 8;
+        if (Xt < p.vp.vpw && Yt < p.vp.vph)
+            p.tileFlags[((size_t)n * p.tfH + ((Yt + p.vp.offy) >> 3)) * p.tfW + ((Xt + p.vp.offx) >> 3)] = ((rowAny >> (laneS * 8)) & 0xFFull) ? 1 : 0;
     }
     if (p.rowCov && laneS == 0) p.rowCov[(size_t)work * kBinTiles + tileRow] = rowAny ? 1 : 0;
     if (kPlain) {
