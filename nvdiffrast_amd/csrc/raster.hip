@@ -472,7 +472,10 @@ __device__ __forceinline__ void hist_add_wave(int* s_hist, int nb, int binsX, ui
 }
 
 // Dynamic LDS: int s_hist[3 * binsX * binsY].
-__global__ __launch_bounds__(256, 5) void k_setup(const SetupParams p_arg, int blocksPerImage)
+#ifndef NVDR_SETUP_WAVES
+#define NVDR_SETUP_WAVES 8
+#endif
+__global__ __launch_bounds__(256, NVDR_SETUP_WAVES) void k_setup(const SetupParams p_arg, int blocksPerImage)
 {
     // The parameter block is read where it lies, in the kernarg segment (a by-value struct handed on by
     // reference is copied into scratch by every thread: measured 94 MB of HBM writes in an earlier version).

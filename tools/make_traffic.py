@@ -11,7 +11,7 @@ NAMES = [("k_setup", "raster_setup"), ("k_order", "raster_order"), ("k_flag_orde
          ("k_fine<false, false, false, false, false, false>", "raster_fine"),
          ("k_interp_raster_grad<", None),        # _da by the instantiation's last argument, below
          ("k_interp_fwd_cols<", "interp_fwd"), ("k_interp_fwd<", None), ("k_interp_grad<", "interp_grad_da"), ("k_raster_grad<true>", "raster_grad_db"), ("k_raster_grad<false>", "raster_grad"),
-         ("k_tex_fwd<", "tex_fwd"), ("k_tex_grad_light_w<", "tex_grad_light"), ("k_tex_grad_light<", "tex_grad_light"), ("k_tex_grad_fold<", "tex_grad_fold"), ("k_tex_grad<", "tex_grad"),
+         ("k_tex_fwd<", "tex_fwd"), ("k_tex_grad_light_w<", "tex_grad_light"), ("k_tex_grad_light<", "tex_grad_light"), ("k_tex_grad_fold<", "tex_grad_fold"), ("k_tex_grad_lean<", "tex_grad"), ("k_tex_grad<", "tex_grad"),
          ("k_mip_grad", "tex_mip_grad"), ("k_aa_discontinuity", "aa_discontinuity"), ("k_aa_analysis", "aa_analysis"), ("k_aa_grad", "aa_grad")]
 
 
