@@ -291,3 +291,41 @@ def test_shared_bins_stress_with_poisoned_exchange_buffers(dr, oracle):
         bad += int((r[..., 3] != want).sum().item())
     torch.cuda.synchronize()
     assert bad == 0
+
+
+@pytest.mark.parametrize("res", [(512, 512), (2048, 2048), (200, 328)])
+def test_long_and_short_edges_share_waves(dr, oracle, res):
+    """k_fine walks coverage two pixels per instruction in 16-bit halves when every edge of a wave's 64 (triangle, tile)
+    pairs is at most 125 px long, and in 32 bits otherwise (raster.hip raster_pairs; tests/test_coverage_pk16.py states the
+    bound).  A soup that interleaves triangles of 1 ... 8 px with triangles of 100 ... 1500 px -- so that waves hold both kinds,
+    tiles are covered completely by the long ones (the immediate depth bound) and the short ones pass through both walks --
+    must give the reference's ids and U32 depths at an ordinary size, at the largest single viewport, and at a size that
+    is no multiple of the tile."""
+    rng = np.random.default_rng(res[0] * 7 + res[1])
+    H, W = res
+    T = 1200
+    c = rng.uniform(-1.05, 1.05, size=(T, 1, 2))
+    small = rng.uniform(1.0, 8.0, size=(T, 1, 1))
+    large = np.exp(rng.uniform(np.log(100.0), np.log(1500.0), size=(T, 1, 1)))
+    size = np.where((np.arange(T) % 3 == 0)[:, None, None], large, small) * (2.0 / max(H, W))
+    ang = rng.uniform(0, 2 * np.pi, size=(T, 1, 1)) + np.array([0, 2.1, 4.2]).reshape(1, 3, 1) + rng.uniform(-0.6, 0.6, size=(T, 3, 1))
+    xy = c + size * np.concatenate([np.cos(ang), np.sin(ang)], -1)
+    z = rng.uniform(-0.95, 0.95, size=(T, 3, 1))
+    pos = np.concatenate([xy, z, np.ones_like(z)], -1).reshape(1, -1, 4).astype(np.float32)
+    # snap some vertices onto pixel centres / corners: edges exactly through samples
+    pos[0, ::7, :2] = np.round(pos[0, ::7, :2] * (W / 2)) / (W / 2)
+    tri = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    ids_o, depth_o = oracle.rasterize_ids(pos, tri, res)
+    ctx = dr.RasterizeCudaContext()
+    with dr.DepthPeeler(ctx, _t(pos), _t(tri), res) as peeler:
+        r, _ = peeler.rasterize_next_layer()
+        r2, _ = peeler.rasterize_next_layer()
+    depth = ctx.cpp_wrapper.peel.cpu().numpy().view(np.uint32)            # layer 0's surface (the peeler swapped them)
+    got = r[..., 3].cpu().numpy()
+    assert (got != ids_o[:, :H, :W].astype(np.float32)).sum() == 0, "triangle ids differ"
+    cov = ids_o[:, :H, :W] > 0
+    assert cov.mean() > 0.5
+    assert (depth[:, :H, :W][cov] != depth_o[:, :H, :W][cov]).sum() == 0, "U32 depth surface differs"
+    plain, _ = dr.rasterize(ctx, _t(pos), _t(tri), res)                    # the non-peeling instantiation
+    assert torch.equal(plain[..., 3], r[..., 3])
+    assert (r2[..., 3] != r[..., 3]).any()                                 # the second layer exists and is another one
