@@ -14,6 +14,18 @@ HIPCC_FLAGS = [
 ]
 
 
+# Per-file flags.  The SLP vectorizer packs neighbouring scalar f32 operations into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32;
+# the packed forms need their operands in aligned register pairs, and in these kernels -- long straight-line per-pixel
+# arithmetic at 64 registers -- the moves that arrange the pairs cost more than the packing saves (r05, interleaved A/B on
+# one box: fused backward with differentials 301 -> 273 us, k_tex_fwd 287 -> 261 us, dense k_fine 148 -> 141 us, fused
+# backward 254 -> 244 us).  interpolate.hip and antialias.hip are 2-3 % faster WITH it and keep it.
+EXTRA_FLAGS = {
+    "raster.hip": ["-fno-slp-vectorize"],
+    "backward_fused.hip": ["-fno-slp-vectorize"],
+    "texture.hip": ["-fno-slp-vectorize"],
+}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -54,7 +66,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
             return obj
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

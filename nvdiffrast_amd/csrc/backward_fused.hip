@@ -167,23 +167,23 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
         if (A_CT == 4) {
             const float4 y = load_streaming((const float4*)pdy);
             const float4 x0 = *(const float4*)a0, x1 = *(const float4*)a1, x2 = *(const float4*)a2;
-            gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y) + y.z * (x0.z - x2.z) + y.w * (x0.w - x2.w);
-            gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y) + y.z * (x1.z - x2.z) + y.w * (x1.w - x2.w);
+            gb0 = dot_diff(y, x0, x2);
+            gb1 = dot_diff(y, x1, x2);
             ymax = __int_as_float((int)max(max(mag_bits(y.x), mag_bits(y.y)), max(mag_bits(y.z), mag_bits(y.w))));
             yreg[r] = y;
         } else if (A_CT == 2) {
             const float2 y = *(const float2*)pdy;
             const float2 x0 = *(const float2*)a0, x1 = *(const float2*)a1, x2 = *(const float2*)a2;
-            gb0 = y.x * (x0.x - x2.x) + y.y * (x0.y - x2.y);
-            gb1 = y.x * (x1.x - x2.x) + y.y * (x1.y - x2.y);
+            gb0 = dot_diff(y, x0, x2);
+            gb1 = dot_diff(y, x1, x2);
             ymax = __int_as_float((int)max(mag_bits(y.x), mag_bits(y.y)));
             yreg[r] = make_float4(y.x, y.y, 0.f, 0.f);
         } else {
             for (int i = 0; i < A; i++) {
                 const float y = pdy[i];
                 const float s2v = a2[i];
-                gb0 += y * (a0[i] - s2v);
-                gb1 += y * (a1[i] - s2v);
+                gb0 = dot_diff(y, a0[i], s2v, gb0);
+                gb1 = dot_diff(y, a1[i], s2v, gb1);
                 ymax = __int_as_float((int)max(mag_bits(ymax), mag_bits(y)));
             }
         }

@@ -64,6 +64,22 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
     return v;
 }
 
+// sum_i y_i (a_i - b_i), the gradient of a barycentric (interpolate.cu:172-182: `gb0 += y * (a0 - a2)` attribute by attribute,
+// which nvcc contracts into one fma per attribute).  Spelled out ONCE, with every operation explicit, for the kernels that
+// compute it (k_interp_grad and the fused k_interp_raster_grad): their g_rast must agree bit for bit -- the stand-in for rast's
+// gradient materialises through the former what the latter used (ops.py _LazyGrad) -- whatever the compiler would otherwise
+// contract, reassociate or pack differently in two translation units built with different flags.
+__device__ __forceinline__ float dot_diff(float y, float a, float b, float acc) {
+#pragma clang fp contract(off)
+    return __fmaf_rn(y, a - b, acc);
+}
+__device__ __forceinline__ float dot_diff(float4 y, float4 a, float4 b) {
+    return dot_diff(y.w, a.w, b.w, dot_diff(y.z, a.z, b.z, dot_diff(y.y, a.y, b.y, dot_diff(y.x, a.x, b.x, 0.f))));
+}
+__device__ __forceinline__ float dot_diff(float2 y, float2 a, float2 b) {
+    return dot_diff(y.y, a.y, b.y, dot_diff(y.x, a.x, b.x, 0.f));
+}
+
 // Hardware f32 atomic add, no return value (global_atomic_add_f32).
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 

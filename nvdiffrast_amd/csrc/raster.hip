@@ -472,10 +472,7 @@ __device__ __forceinline__ void hist_add_wave(int* s_hist, int nb, int binsX, ui
 }
 
 // Dynamic LDS: int s_hist[3 * binsX * binsY].
-#ifndef NVDR_SETUP_WAVES
-#define NVDR_SETUP_WAVES 8
-#endif
-__global__ __launch_bounds__(256, NVDR_SETUP_WAVES) void k_setup(const SetupParams p_arg, int blocksPerImage)
+__global__ __launch_bounds__(256, 8) void k_setup(const SetupParams p_arg, int blocksPerImage)
 {
     // The parameter block is read where it lies, in the kernarg segment (a by-value struct handed on by
     // reference is copied into scratch by every thread: measured 94 MB of HBM writes in an earlier version).
@@ -911,43 +908,10 @@ struct FineParams {
 
 
 constexpr int kEarlyZTiles = 4;                          // tile bounds a wave refreshes per batch of 64 pairs once covered tiles see more pairs (k_fine)
-#if !NVDR_FINE_DIRECT
-constexpr int kQueueSize = 128;
-#endif
 
-// Build-time variants of k_fine's pair stage (tools/build_variant.sh passes -D flags for A/B runs on one GPU box):
-//   NVDR_FINE_DIRECT   1: a wave's 64 pairs go from the lanes that numbered them straight into raster_pairs (registers);
-//                      0: through the per-wave LDS ring of round 2-4 (a leftover of the per-tile rejection test that filtered
-//                         pairs before they were queued: with every pair kept, the ring is a write and a read back per pair)
-//   NVDR_FINE_BSTART   1: the list entry of a wave's first pair comes from a table wave 0 fills next to the prefix sum (the entry
-//                         holding every 64th pair), the other 63 from one read of the next 64 prefixes and a wave-wide OR;
-//                      0: a 9-step binary search per lane over the prefix array (nine dependent LDS round trips per batch)
-//   NVDR_FINE_FULLZ    1: a mask that covers its tile completely lowers the tile's depth bound at once (FineRaster.inl:19-34
-//                         updateTileZMax without the scan): the plane's largest corner value, one scalar computation + one ds_min_u32
-//   NVDR_FINE_PK16     1: coverage of two pixels per instruction in 16-bit halves (raster_pairs); 0: one pixel per 32-bit step
-//   NVDR_FINE_COLD     while no tile of the bin has a finite bound, a wave refreshes one tile's bound every NVDR_FINE_COLD-th batch
-//   NVDR_FINE_ADAPT    1: ... and after every batch that held a mask with more than eight fragments
-#ifndef NVDR_FINE_DIRECT
-#define NVDR_FINE_DIRECT 1
-#endif
-#ifndef NVDR_FINE_BSTART
-#define NVDR_FINE_BSTART 1
-#endif
-#ifndef NVDR_FINE_FULLZ
-#define NVDR_FINE_FULLZ 1
-#endif
-#ifndef NVDR_FINE_PK16
-#define NVDR_FINE_PK16 1
-#endif
-#ifndef NVDR_FINE_CLEAR_ROWS
-#define NVDR_FINE_CLEAR_ROWS 1
-#endif
-#ifndef NVDR_FINE_COLD
-#define NVDR_FINE_COLD 8
-#endif
-#ifndef NVDR_FINE_ADAPT
-#define NVDR_FINE_ADAPT 1
-#endif
+// Refresh cadence of the per-tile depth bounds (k_fine): kEarlyZTiles tiles per batch of 64 pairs once covered tiles see more
+// pairs; one after a batch that held a mask with more than eight fragments; otherwise one every kColdRefresh batches.
+constexpr int kColdRefresh = 8;
 
 struct FineShared {
     uint32_t slot[kListCap];                               // bin triangle list: record slot of each entry
@@ -955,11 +919,7 @@ struct FineShared {
     unsigned long long key[kBinTiles][kBinTiles][64];      // per-pixel visibility keys of the bin [tileY][tileX][pixel]
     uint16_t pfx[kListCap + 64];                           // exclusive prefix of the entries' (triangle, tile) pair counts (<= 448 x 64)
     uint32_t tileZ[kBinTiles * kBinTiles];                 // per tile: an upper bound (upper half + 1) of what every pixel's depth will end up at most
-#if NVDR_FINE_DIRECT
     uint16_t bstart[kListCap];                             // per 64 pairs: the list entry that holds pair 64 k (at most kListCap x 64 pairs)
-#else
-    uint16_t queue[kFineWaves][kQueueSize];                // per-wave ring of surviving pairs: entry | tileX << 9 | tileY << 12
-#endif
     int count;
     int pending;                                           // some wave has not scanned its share of the bin's slot range to the end
     int totalPairs;
@@ -1029,7 +989,6 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
     if (DBG && (p.dbg & 256)) { if (q0.x == 0x12345u && q3.w == 77u) sh.key[0][0][lane] = q1.x; return 0; }      // experiment: no coverage, no fragments
     // Coverage.  Bit y * 8 + x of the mask is pixel (x, y) of the tile.
     uint64_t m;
-#if NVDR_FINE_PK16
     // Two pixels per instruction, in 16-bit halves.  A, B are multiples of 16 (emit_record), so with C = 16 c1 + c0, 0 <= c0 < 16,
     // E >= 0  <=>  E' = c1 + (A/16) X + (B/16) Y >= 0: four bits less.  Only the SIGN of E' matters, and over the tile's pixels E'
     // moves by at most 7 (|A'| + |B'|) from its value at the origin, so that value can be clamped to +-16000 as long as that
@@ -1065,20 +1024,14 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
         const uint32_t outLo = __builtin_amdgcn_perm(accB, accA, 0x05040100u);      // rows 0..3
         const uint32_t outHi = __builtin_amdgcn_perm(accB, accA, 0x07060302u);      // rows 4..7
         m = act ? ~(((uint64_t)outHi << 32) | outLo) : 0ull;
-    } else
-#endif
-    {
-        // one pixel per step in 32 bits (NVDR_FINE_PK16: the rare wave that holds an edge longer than 125 px -- rolled up, so that
+    } else {
+        // one pixel per step in 32 bits (the rare wave that holds an edge longer than 125 px -- rolled up, so that
         // it costs the common path neither registers nor code)
         uint32_t half[2] = {0u, 0u};             // rows 0..3, rows 4..7 (sign bits = outside), first pixel in the top bit
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             uint32_t bits = 0u;
-#if NVDR_FINE_PK16
 #pragma unroll 1
-#else
-#pragma unroll
-#endif
             for (int y = 0; y < 4; y++) {
                 uint32_t r0 = e0, r1 = e1, r2 = e2;
 #pragma unroll
@@ -1144,7 +1097,6 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
             const uint32_t szx = (uint32_t)__builtin_amdgcn_readlane((int)zx, src), szy = (uint32_t)__builtin_amdgcn_readlane((int)zy, src);
             const uint32_t sd0 = (uint32_t)__builtin_amdgcn_readlane((int)d0, src), sidk = (uint32_t)__builtin_amdgcn_readlane((int)idk, src);
             const int stile = __builtin_amdgcn_readlane(tile, src);
-#if NVDR_FINE_FULLZ
             if (!PEEL && ezOn && sm == ~0ull) {
                 // The triangle covers all 64 pixels of the tile: every pixel's key ends up at most at this triangle's depth there,
                 // so the plane's largest corner value bounds the tile at once (the reference's updateTileZMax, FineRaster.inl:19-34,
@@ -1154,7 +1106,6 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
                 const uint32_t cmax = sd0 + 7u * (uint32_t)max((int)szx, 0) + 7u * (uint32_t)max((int)szy, 0);
                 if (lane == 0) atomicMin(&sh.tileZ[stile], (cmax >> 16) + 1u);
             }
-#endif
             if (__builtin_amdgcn_inverse_ballot_w64(sm)) {                 // the mask IS the execution mask
                 const uint32_t depth = sd0 + __umul24(szx & 0xFFFFFFu, xl) + (__umul24(szx >> 24, xl) << 24)
                                            + __umul24(szy & 0xFFFFFFu, yl) + (__umul24(szy >> 24, yl) << 24);
@@ -1250,7 +1201,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         int lane;                                              // taken afresh (opaque): nothing of this stays live across the raster stage
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         const int n2 = packed >> 10, by2 = (packed >> 5) & 31, bx2 = packed & 31;
-#if NVDR_FINE_CLEAR_ROWS
         // a wave's eight pixel rows of the bin, ONE ROW PER STORE: 64 lanes x 16 B = 1 KiB contiguous (tile by tile a store was
         // eight 128-byte pieces 8 KB apart)
         const int X = bx2 * kBinTiles * 8 + lane;
@@ -1267,20 +1217,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         }
         if (q.tileFlags && lane < kBinTiles && (bx2 * kBinTiles + lane) * 8 < q.vp.vpw)        // lane t: the row's tile t
             q.tileFlags[((size_t)n2 * q.tfH + ((Y0 + q.vp.offy) >> 3)) * q.tfW + (((bx2 * kBinTiles + lane) * 8 + q.vp.offx) >> 3)] = 0;
-#else
-        const int Y = (by2 * kBinTiles + wave / kWavesPerRow) * 8 + (lane >> 3);
-        if (Y >= q.vp.vph) return;
-#pragma unroll 1
-        for (int tt = 0; tt < kTilesPerWave; tt++) {
-            const int X = (bx2 * kBinTiles + (wave % kWavesPerRow) * kTilesPerWave + tt) * 8 + (lane & 7);
-            if (X >= q.vp.vpw) continue;
-            const size_t pidx = ((size_t)n2 * q.H + (Y + q.vp.offy)) * q.W + (X + q.vp.offx);
-            ((float4*)q.out)[pidx] = make_float4(0.f, 0.f, 0.f, 0.f);
-            store_streaming((float4*)q.out_db + pidx, make_float4(0.f, 0.f, 0.f, 0.f));
-            if (q.tileFlags && lane == 0)                      // (lane 0 = the tile's first pixel: inside the viewport here)
-                q.tileFlags[((size_t)n2 * q.tfH + ((Y + q.vp.offy) >> 3)) * q.tfW + ((X + q.vp.offx) >> 3)] = 0;
-        }
-#endif
         if (q.rowCov && lane == 0) q.rowCov[((size_t)(n2 * q.binsY + by2) * q.binsX + bx2) * kBinTiles + wave / kWavesPerRow] = 0;
     };
     // Empty bins are pure stores, and in the heavy-first order they all come last: 300 MB of zeros at the headline batch
@@ -1466,7 +1402,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 const int base = incl - sum;
 #pragma unroll
                 for (int i = 0; i < kPer; i++) { const int j = lane * kPer + i; if (j <= cnt) sh.pfx[j] = (uint16_t)(base + local[i]); }
-#if NVDR_FINE_DIRECT && NVDR_FINE_BSTART
                 // the entry that holds every 64th pair: entry j covers pairs [start, end); the first multiple of 64 at or after its
                 // start is inside it at most once (an entry has at most 64 pairs)
 #pragma unroll
@@ -1476,7 +1411,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     const int k64 = (start + 63) >> 6;
                     if (j < cnt && (k64 << 6) < end) sh.bstart[k64] = (uint16_t)j;
                 }
-#endif
                 if (lane == 63) sh.totalPairs = incl;
             }
             __syncthreads();
@@ -1487,13 +1421,11 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                 // cull's registers cost that instantiation 8 % at a million triangles, 0.245 -> 0.263 ms)
                 const bool ezOn = !LIST && !(DBG && (p.dbg & 32));
                 int turn = wave;                            // the tile whose depth bound this wave refreshes next
-#if NVDR_FINE_DIRECT
                 int cold = 0;                               // batches since this wave last refreshed a bound with nothing to cull
                 for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
                     const int q = q0 + lane;
                     const bool act = q < total;
                     int j;
-#if NVDR_FINE_BSTART
                     {
                         // entry s holds pair q0 (wave 0's table); the entries s + 1 ... that START inside this batch each set one
                         // bit of a wave-wide mask (entries have at least one pair each: starts are distinct), and a pair's entry is s
@@ -1510,18 +1442,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                         j = s + mask_rank(M) + (int)((M >> lane) & 1ull);
                         if (!act) j = 0;
                     }
-#else
-                    {
-                        // entry j = the last one whose prefix is <= q (entries without pairs share a prefix
-                        // with their successor and are skipped by taking the last)
-                        int lo = 0, hi = cnt - 1;
-                        while (__ballot(lo < hi)) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (lo < hi) { if ((int)sh.pfx[mid] <= q) lo = mid; else hi = mid - 1; }
-                        }
-                        j = act ? lo : 0;
-                    }
-#endif
                     int x0, y0, nx, ny;
                     pair_box(sh.box[j], x0, y0, nx, ny);
                     const int k = act ? q - (int)sh.pfx[j] : 0;
@@ -1531,11 +1451,11 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                     const int batch = raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, act, (uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12),
                                                               btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
                     // (kEarlyZTiles tiles per batch once covered tiles see more pairs; one after a batch with a large mask -- large
-                    // triangles are what covers tiles; otherwise one every NVDR_FINE_COLD batches: a mesh of small triangles without
+                    // triangles are what covers tiles; otherwise one every kColdRefresh batches: a mesh of small triangles without
                     // overdraw pays next to nothing -- refreshing after every batch was 9 us of the headline's 145, r05a)
                     if (ezOn) {
-                        int nref = (batch & 1) ? kEarlyZTiles : (NVDR_FINE_ADAPT && (batch & 2)) ? 1 : 0;
-                        if (nref == 0 && ++cold >= NVDR_FINE_COLD) { cold = 0; nref = 1; }
+                        int nref = (batch & 1) ? kEarlyZTiles : (batch & 2) ? 1 : 0;
+                        if (nref == 0 && ++cold >= kColdRefresh) { cold = 0; nref = 1; }
 #pragma unroll 1
                         for (int rt = 0; rt < nref; rt++) {
                             refresh_tile_bound(sh, turn);
@@ -1543,50 +1463,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
                         }
                     }
                 }
-#else
-                int head = 0, qn = 0;
-                for (int q0 = wave * 64; q0 < total; q0 += kFineWaves * 64) {
-                    const int q = q0 + lane;
-                    const bool act = q < total;
-                    // entry j = the last one whose prefix is <= q (entries without pairs share a prefix
-                    // with their successor and are skipped by taking the last)
-                    int lo = 0, hi = cnt - 1;
-                    while (__ballot(lo < hi)) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (lo < hi) { if ((int)sh.pfx[mid] <= q) lo = mid; else hi = mid - 1; }
-                    }
-                    const int j = act ? lo : 0;
-                    int x0, y0, nx, ny;
-                    pair_box(sh.box[j], x0, y0, nx, ny);
-                    const int k = act ? q - (int)sh.pfx[j] : 0;
-                    const int ky = (nx > 1) ? (int)(((float)k + 0.5f) / (float)nx) : k;   // exact for k < 64, nx <= 8
-                    const int kx = k - ky * nx;
-                    const int tx = x0 + kx - btx0, tyl = y0 + ky - bty0;
-                    const bool keep = act;
-                    const uint64_t m = __ballot(keep);
-                    if (keep) sh.queue[wave][(head + qn + mask_rank(m)) & (kQueueSize - 1)] =
-                        (uint16_t)((uint32_t)j | ((uint32_t)tx << 9) | ((uint32_t)tyl << 12));
-                    qn += __popcll(m);
-                    if (qn >= 64) {
-                        __builtin_amdgcn_wave_barrier();
-                        const bool hotBatch = 1 & raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, true, sh.queue[wave][(head + lane) & (kQueueSize - 1)], btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
-                        __builtin_amdgcn_wave_barrier();
-                        head = (head + 64) & (kQueueSize - 1);
-                        qn -= 64;
-                        // (one tile per batch while nothing is there to cull, kEarlyZTiles once covered tiles see more pairs)
-#pragma unroll 1
-                        for (int rt = 0; rt < (hotBatch ? kEarlyZTiles : ezOn ? 1 : 0); rt++) {
-                            refresh_tile_bound(sh, turn);
-                            turn = (turn + kFineWaves) & (kBinTiles * kBinTiles - 1);
-                        }
-                    }
-                }
-                if (qn > 0) {
-                    __builtin_amdgcn_wave_barrier();
-                    raster_pairs<PEEL, DBG>(sh, p, grec, lane, n, lane < qn, sh.queue[wave][(head + lane) & (kQueueSize - 1)], btx0, bty0, DBG ? &dbgSurv : nullptr, ezOn);
-                    __builtin_amdgcn_wave_barrier();
-                }
-#endif
             }
             if (DBG && p.dbgbuf) { unsigned long long tr = wall_clock64(); if (p.dbg & 64) { tstamp[2] += (unsigned long long)sh.totalPairs; tstamp[3] += dbgSurv; dbgSurv = 0; } else { tstamp[2] += tf1 - tf0; tstamp[3] += tr - tf1; } }
             __syncthreads();

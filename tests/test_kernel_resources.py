@@ -31,8 +31,9 @@ def _kernel_body(text, mangled):
 
 def _metadata(tmp_path, src):
     out = tmp_path / (src + ".s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only",
-           "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(CSRC, src)]
+    from nvdiffrast_amd import _build
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fhip-fp32-correctly-rounded-divide-sqrt"] + _build.EXTRA_FLAGS.get(src, []) + \
+          ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(CSRC, src)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     text = out.read_text()

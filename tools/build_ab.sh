@@ -7,6 +7,7 @@ cd "$(dirname "$0")/../nvdiffrast_amd"
 src=$1; shift
 ls build/*.hip.o >/dev/null
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I../include -Icsrc"
+case "$src" in raster.hip|backward_fused.hip|texture.hip) FLAGS="$FLAGS -fno-slp-vectorize";; esac      # (nvdiffrast_amd/_build.py EXTRA_FLAGS)
 for spec in "$@"; do
   name=${spec%%=*}; arg=${spec#*=}
   mkdir -p build/ab_$name
