@@ -1,5 +1,12 @@
+#!/usr/bin/env python3
+"""Development (round 5, docs/NOTES.md 9.3): would a DENSE texel window per mip level hold the taps of a 16x16-pixel block of config 3?
+CPU only: uv / uv_da of the benchmark mesh from the oracle, then per block the share of pixels with a tap outside a 34 / 18 / 10
+window set anchored at the block's smallest texture coordinate (what k_tex_grad_win did), outside windows derived from the block's
+uv bounding box (S1), and outside per-level corners with a full window for EVERY level (S2), plus the number of distinct mip
+levels per block.      python tools/exp_texwin_sim.py"""
+import os
 import numpy as np, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from nvdiffrast_amd.utils import m10k_batch
 b=m10k_batch(4)
