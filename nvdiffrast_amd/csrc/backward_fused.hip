@@ -242,6 +242,9 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
     for (int r = 0; r < kFuRows; r++) {
         if (__ballot(ok[r]) == 0) continue;
         const RunScan rs(tri[r], ok[r]);
+        // (no lane continues a run -- a mesh of sub-pixel triangles -- : every lane is its own run's tail and the seven scans
+        // of the row, 84 DPP multiply-adds, would add zeros)
+        const bool scanning = !direct && rs.any_merge();
         const bool emit = direct ? ok[r] : rs.tail;
         int s0 = -1, s1 = -1, s2 = -1;
         if (emit && !direct) tab.find3(vi[r][0], vi[r][1], vi[r][2], s0, s1, s2);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
             if (kRegs) y = i == 0 ? yreg[r].x : i == 1 ? yreg[r].y : i == 2 ? yreg[r].z : yreg[r].w;
             else       y = ok[r] ? pdy[i] : 0.f;
             float v0 = c0 * y, v1 = c1 * y, v2 = c2 * y;
-            if (!direct) rs.scan3(v0, v1, v2);
+            if (scanning) rs.scan3(v0, v1, v2);
             put3(i, v0, v1, v2);
         }
         if (ENABLE_DA) {
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
                 float du = d.x * db.x + d.y * db.y;
                 float dv = d.x * db.z + d.y * db.w;
                 float dw = -du - dv;
-                if (!direct) rs.scan3(du, dv, dw);
+                if (scanning) rs.scan3(du, dv, dw);
                 put3(j, du, dv, dw);
             }
         }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(kFuThreads, ENABLE_DA ? 6 : 8) void k_interp_raster
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 float v0 = g[r][k * 3 + 0], v1 = g[r][k * 3 + 1], v2 = g[r][k * 3 + 2];
-                if (!direct) rs.scan3(v0, v1, v2);
+                if (scanning) rs.scan3(v0, v1, v2);
                 if (!emit) continue;
                 const int s = k == 0 ? s0 : k == 1 ? s1 : s2;
                 if (s >= 0) {

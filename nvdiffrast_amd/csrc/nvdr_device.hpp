@@ -441,12 +441,16 @@ struct VertexTable {
         for (int i = tid; i < slots; i += nthreads) keys[i] = 0u;
         for (int i = tid; i < slots * stride; i += nthreads) vals[i] = 0ull;
     }
-    // Slot of `vertex` (inserting it if needed) or -1 when the probe budget is exhausted.
+    // Slot of `vertex` (inserting it if needed) or -1 when the probe budget is exhausted.  Six probes: a block of an ordinary mesh
+    // claims a tenth of the table and finds its slot with the first or second; a block of sub-pixel triangles (a million-triangle
+    // mesh: up to 3072 vertices for 512 slots) cannot be held anyway, and with sixteen probes every lane walked sixteen dependent
+    // compare-and-swaps to learn that before taking the direct path.
+    static constexpr int kProbes = 6;
     __device__ __forceinline__ int find(int vertex) const {
         const uint32_t key = (uint32_t)vertex + 1u;
         uint32_t h = (key * 0x9E3779B1u) >> 8;
 #pragma unroll 1
-        for (int probe = 0; probe < 16; probe++) {
+        for (int probe = 0; probe < kProbes; probe++) {
             h &= (uint32_t)(slots - 1);
             uint32_t old = atomicCAS(&keys[h], 0u, key);
             if (old == 0u || old == key) return (int)h;
@@ -470,7 +474,7 @@ struct VertexTable {
     }
     __device__ __forceinline__ int probe_on(uint32_t key, uint32_t h) const {
 #pragma unroll 1
-        for (int probe = 1; probe < 16; probe++) {
+        for (int probe = 1; probe < kProbes; probe++) {
             h &= (uint32_t)(slots - 1);
             const uint32_t old = atomicCAS(&keys[h], 0u, key);
             if (old == 0u || old == key) return (int)h;
