@@ -24,13 +24,13 @@
 //            (ballot/mbcnt prefix sums).  (2) The list's (triangle, 8x8 tile) pairs are numbered
 //            by a prefix sum and dealt to the waves 64 at a time, ONE LANE PER PAIR: the lane
 //            walks its triangle's three edge functions over the tile's 64 pixel centres with
-//            integer adds into a 64-bit coverage mask, then pops the set bits (masks with many
+//            integer adds (two pixels per instruction, in 16-bit halves) into a 64-bit coverage mask, then pops the set bits (masks with many
 //            fragments: the whole wave, one lane per pixel, the mask as execution mask) and merges
 //            depth << 32 | ~id into the tile's per-pixel keys with an LDS 64-bit atomic min:
 //            minimum depth wins, ties go to the highest triangle id, which is exactly what
 //            the reference's in-order LEQUAL ROP produces (FineRaster.inl:152-172,349-361)
-//            without needing any ordering.  (3) One lane per pixel: the winning id goes
-//            straight into the pixel shader (rasterize.cu:15-114) in the same kernel, so the
+//            without needing any ordering.  (3) One lane per pixel column, one image row of the bin per store: the winning id
+//            goes straight into the pixel shader (rasterize.cu:15-114) in the same kernel, so the
 //            id/depth surfaces never touch HBM (the depth surface is stored only for depth
 //            peeling).  A bin shared by several workgroups: every part rasterises its share of the
 //            bin's slot range, the parts' key arrays meet in memory (returning device-scope atomics
@@ -66,7 +66,7 @@ constexpr int kHelpersPerChunk = kSplitsPerChunk * (kSplitMaxParts - 1);
 constexpr int kListSplitTris = 2048, kListSplitPart = 1024, kListSplitMaxParts = 127, kListHelpersPerChunk = 480;
 // split descriptor: parts | part << 7 | split number << 14
 constexpr int kPartBits = 7, kPartMask = (1 << kPartBits) - 1;
-constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in the pair ring)
+constexpr int kListCap    = 448;                         // LDS triangle list capacity (< 512: 9-bit entry numbers in a pair's code)
 constexpr int kListMinTris = 32768;                      // meshes of at least this many triangles get per-bin triangle lists (k_binscan / k_binfill)
 constexpr int kListScanFactor = 8, kListScanBias = 2048; // a bin takes its list instead of scanning its slot range when range > factor * triangles + bias
 constexpr int kFillThreads = 1024, kFillSlots = kFillThreads * 4;   // k_binfill: slots per workgroup
@@ -1373,8 +1373,6 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
             unsigned long long tf1 = (DBG && p.dbgbuf) ? wall_clock64() : 0;
             if (DBG) { tstamp[1] += 1; tstamp[4] += cnt; }
 
-            // ---- raster: every wave takes list chunks, queues their (triangle, tile) pairs and
-            //      rasterises them 64 at a time into the shared key arrays (LDS atomics) -------------
             // ---- raster: the list's (triangle, tile) pairs are numbered through a prefix sum of the
             //      entries' pair counts; waves take 64 consecutive pair numbers at a time (lane = pair),
             //      so work is balanced over all waves whatever the triangles' shapes, and rasterise
