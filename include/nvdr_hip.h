@@ -110,7 +110,9 @@ int nvdr_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* rang
                        float* out, float* out_db, uint8_t* tile_flags, nvdrStream_t stream);
 
 /* grad_pos (shape of pos) must be zero-filled by the caller (reference: zeros_like,
- * torch_rasterize.cpp:237).  ddb == NULL selects the rasterize_grad variant. */
+ * torch_rasterize.cpp:237).  ddb == NULL selects the rasterize_grad variant.  dy == NULL (with ddb): only ddb's share is
+ * ADDED to grad_pos -- for a caller that holds dy's share already (nvdr_interpolate_rasterize_grad); by linearity the sum
+ * is rasterize_grad_db(dy, ddb). */
 int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const float* out,
                         const float* dy, const float* ddb,
                         int instance_mode, int N, int V, int T, int H, int W,

@@ -1683,23 +1683,30 @@ constexpr int kGradSlots = 512;
 
 struct PixelGrad { int tri, vi0, vi1, vi2; float g[9]; };
 
-template <bool ENABLE_DB>
+template <bool ENABLE_DB, bool DB_ONLY>
 __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const float4* __restrict__ vb, int px, int py, int pz, PixelGrad& r)
 {
     if (px >= p.W) return false;
     if (p.flags.empty(pz, py, px)) return false;                      // nothing visible in this 8x8 tile: rast is not read
     const size_t pidx = ((size_t)pz * p.H + py) * p.W + px;
+    float4 ddb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int grad_all_ddb = 0;
+    if (DB_ONLY) {
+        // dy == NULL: only rast_db's gradient contributes (the caller holds dy's share already).  It is looked at FIRST: where it
+        // is all zeros -- the tensor autograd materialises for an output nobody used -- rast is not read either.
+        ddb = ((const float4*)p.ddb)[pidx];
+        grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
+        if ((((uint32_t)grad_all_ddb) << 1) == 0u) return false;
+    }
     const int triIdx = float_to_triidx(p.out[pidx * 4 + 3]) - 1;
     if (triIdx < 0 || triIdx >= p.T) return false;
     // Upstream gradients are fetched for covered pixels only (background rows of dy never leave HBM);
     // these loads travel together with the index loads.
-    const float2 dy = ((const float2*)p.dy)[pidx * 2];
-    float4 ddb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ENABLE_DB) ddb = ((const float4*)p.ddb)[pidx];
+    const float2 dy = DB_ONLY ? make_float2(0.f, 0.f) : ((const float2*)p.dy)[pidx * 2];
+    if (ENABLE_DB && !DB_ONLY) ddb = ((const float4*)p.ddb)[pidx];
     const int vi0 = p.tri[triIdx * 3 + 0], vi1 = p.tri[triIdx * 3 + 1], vi2 = p.tri[triIdx * 3 + 2];
     const int grad_all_dy = __float_as_int(dy.x) | __float_as_int(dy.y);
-    int grad_all_ddb = 0;
-    if (ENABLE_DB) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
+    if (ENABLE_DB && !DB_ONLY) grad_all_ddb = __float_as_int(ddb.x) | __float_as_int(ddb.y) | __float_as_int(ddb.z) | __float_as_int(ddb.w);
     if ((((uint32_t)(grad_all_dy | grad_all_ddb)) << 1) == 0u) return false;          // all +-0 (:143-148)
     if (vi0 < 0 || vi0 >= p.V || vi1 < 0 || vi1 >= p.V || vi2 < 0 || vi2 >= p.V) return false;   // (short-circuit form: measured faster here than indices_ok)
     r.tri = triIdx; r.vi0 = vi0; r.vi1 = vi1; r.vi2 = vi2;
@@ -1712,7 +1719,7 @@ __device__ __forceinline__ bool raster_pixel_grad(const GradParams& p, const flo
     return true;
 }
 
-template <bool ENABLE_DB>
+template <bool ENABLE_DB, bool DB_ONLY = false>
 __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad(const GradParams p, int gx, int gy)
 {
     __shared__ uint32_t s_keys[kGradSlots];
@@ -1722,14 +1729,29 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
     int bx, by, pz;
     if (p.flags.order ? !decode_block_ordered(p.flags, gx, gy, kGradBlockW, kGradBlockH, bx, by, pz)
                       : !decode_block(gx, gy, p.N, bx, by, pz)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = bx * kGradBlockW + lane;
+    const int row0 = by * kGradBlockH + wave * kGradRowsPerWave;
+    if (DB_ONLY) {
+        // The usual caller of this variant holds the zeros autograd materialised for a rast_db nobody used (_plugin.py, "fused
+        // backward"): look at the block's ddb first -- four loads in flight per lane, nothing else set up -- and leave if it is
+        // all zeros.  (A block that stays reads its ddb again below, from L2.)
+        uint32_t any = 0u;
+#pragma unroll
+        for (int r = 0; r < kGradRowsPerWave; r++) {
+            const int py = row0 + r;
+            if (px < p.W && py < p.H && !p.flags.empty(pz, py, px)) {
+                const float4 d = ((const float4*)p.ddb)[((size_t)pz * p.H + py) * p.W + px];
+                any |= __float_as_uint(d.x) | __float_as_uint(d.y) | __float_as_uint(d.z) | __float_as_uint(d.w);
+            }
+        }
+        if (!__syncthreads_or((any << 1) != 0u)) return;
+    }
     VertexTable tab{s_keys, s_vals, kGradSlots, 3};
     tab.clear(threadIdx.x, kGradThreads);
     if (threadIdx.x == 0) { s_max = 0u; s_used = 0u; }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = bx * kGradBlockW + lane;
-    const int row0 = by * kGradBlockH + wave * kGradRowsPerWave;
     const size_t voff = p.instance ? (size_t)pz * p.V : 0;
     const float4* vb = (const float4*)p.pos + voff;
     float* gout = p.grad + voff * 4;
@@ -1741,7 +1763,7 @@ __global__ __launch_bounds__(kGradThreads, ENABLE_DB ? 4 : 6) void k_raster_grad
 #pragma unroll
     for (int r = 0; r < kGradRowsPerWave; r++) {
         const int py = row0 + r;
-        ok[r] = (py < p.H) && raster_pixel_grad<ENABLE_DB>(p, vb, px, py, pz, pg[r]);
+        ok[r] = (py < p.H) && raster_pixel_grad<ENABLE_DB, DB_ONLY>(p, vb, px, py, pz, pg[r]);
         if (ok[r]) {
 #pragma unroll
             for (int k = 0; k < 9; k++) um = max(um, mag_bits(pg[r].g[k]));
@@ -2102,7 +2124,7 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (debug_flags() & 2097152) return NVDR_OK;             // development: host-overhead measurement, nothing is launched (tools/host_profile.py)
-    NVDR_REQUIRE(pos && tri && out && dy && grad_pos, "rasterize_grad: null pointer");
+    NVDR_REQUIRE(pos && tri && out && (dy || ddb) && grad_pos, "rasterize_grad: null pointer");
     NVDR_REQUIRE(N > 0 && H > 0 && W > 0, "resolution must be [>0, >0, >0]");
     NVDR_REQUIRE(V > 0 && T > 0, "rasterize_grad: empty input");
     NVDR_REQUIRE(!((uintptr_t)pos & 15), "pos input tensor not aligned to float4");
@@ -2121,8 +2143,9 @@ extern "C" int nvdr_rasterize_grad(const float* pos, const int32_t* tri, const f
     NVDR_REQUIRE(total < (1ll << 30), "rasterize_grad: too many pixel blocks");
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
     {
-        ProfileScope ps(ddb ? "raster_grad_db" : "raster_grad", stream);
-        if (ddb) hipLaunchKernelGGL(k_raster_grad<true>,  grid, dim3(kGradThreads), 0, stream, p, gx, gy);
+        ProfileScope ps(!dy ? "raster_grad_db_only" : ddb ? "raster_grad_db" : "raster_grad", stream);
+        if (!dy) hipLaunchKernelGGL((k_raster_grad<true, true>), grid, dim3(kGradThreads), 0, stream, p, gx, gy);   // ddb's share only, ADDED to grad_pos
+        else if (ddb) hipLaunchKernelGGL(k_raster_grad<true>,  grid, dim3(kGradThreads), 0, stream, p, gx, gy);
         else     hipLaunchKernelGGL(k_raster_grad<false>, grid, dim3(kGradThreads), 0, stream, p, gx, gy);
     }
     NVDR_LAUNCH_CHECK();

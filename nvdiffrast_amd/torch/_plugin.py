@@ -15,6 +15,7 @@ import os
 import weakref
 
 import torch
+from torch.utils._pytree import tree_map as _tree_map
 
 from .. import _capi
 
@@ -336,6 +337,7 @@ def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     state.mark_clean(layout)
     state.last_flags = flags
     _attach_tiles(out, flags, "rast")
+    out._nvdr_tiles.origin = _FwdOrigin(pos, tri, state, out, out_db)
     return out, out_db
 
 
@@ -370,11 +372,12 @@ def tile_flag_verifications():
 
 class _TileRecord:
     """kind "rast": flag 0 = no pixel of the tile shows a triangle; kind "zero": flag 0 = every element of the tile is zero."""
-    __slots__ = ("flags", "ptr", "version", "shape", "kind", "__weakref__")
+    __slots__ = ("flags", "ptr", "version", "shape", "kind", "origin", "__weakref__")
 
     def __init__(self, flags, t, kind):
         # (full shape AND strides: an alias of the same storage with another last dimension or layout does not inherit the record)
         self.flags, self.ptr, self.version, self.shape, self.kind = flags, t.data_ptr(), t._version, (tuple(t.shape), t.stride()), kind
+        self.origin = None                 # kind "rast": _FwdOrigin, set by rasterize_fwd_cuda
 
     def still(self, t):
         return t.data_ptr() == self.ptr and t._version == self.version and (tuple(t.shape), t.stride()) == self.shape
@@ -464,18 +467,185 @@ def _flags_ok(fn, tile_flags, n, h, w, dev):
     return tile_flags.data_ptr()
 
 
+# ---- fused backward of rasterize -> interpolate ------------------------------------------------------------------------------
+# The library has one kernel for interpolate_grad[_da] + rasterize_grad[_db] (interpolate_rasterize_grad below).  The operator
+# layer of this package drives it with its own bookkeeping (ops.py _RasterOrigin); a caller that binds this module exactly like
+# the reference's ops.py binds _nvdiffrast_c calls interpolate_grad[_da] and, later in the same
+# backward pass, rasterize_grad[_db] -- so the same exchange is done HERE between those two entry points:
+#   interpolate_grad[_da](attr, rast, ...)   rast is what rasterize_fwd_cuda returned (its record says so: _FwdOrigin), untouched,
+#       interpolated once, and pos requires a gradient: the fused kernel computes g_attr AND the position gradient; g_rast
+#       (and g_rast_db) are not written -- the caller gets stand-ins that compute them if anybody looks (_LazyGrad);
+#   rasterize_grad[_db](pos, tri, out, dy, ddb)   dy is that very stand-in, unedited (autograd delivers the object itself when
+#       nothing else contributed to rast's gradient): the prepared gradient is returned.  A `ddb` that is an ordinary tensor --
+#       the zeros the reference's ops.py lets autograd materialise for an unused rast_db (its backward, ops.py:84-90), or a real
+#       gradient from another consumer -- adds its share in a pass that reads ddb first and rast only where ddb is non-zero
+#       (nvdr_rasterize_grad with dy == NULL).  Anything else arriving: the stand-in is materialised and the two-kernel path
+#       runs as if nothing had been prepared (and the context stops preparing, as in ops.py).
+# Calls that pass `fuse=False` (this package's ops.py: it does the same one level up) never take part.
+
+class _LazyGrad(torch.Tensor):
+    """The gradient of `rast` (or `rast_db`) that interpolate's backward returns when the fused kernel has already turned it into
+    the position gradient: a tensor whose VALUES are computed only if somebody looks at them.
+
+    In the graph rasterize -> interpolate the only reader of rast's gradient is rasterize's backward, and that one does not need
+    it any more (ops.py _RasterOrigin, _FwdOrigin below) -- yet it is 16 B/pixel of stores (268 MB of the 297 MB the fused kernel wrote at the
+    headline batch), zeros for three quarters of them.  So the kernel does not write it, and autograd gets this stand-in: shape,
+    dtype and device of the real thing (a stride-0 view of one zero, so it has storage for the engine's stream bookkeeping), and
+    a __torch_dispatch__ that replaces it by the real gradient -- computed then by the reference's own two-kernel formulation,
+    interpolate_grad[_da] -- in front of ANY operation that touches it: autograd's summation when rast's gradient has other
+    contributors, the clone of retain_grad(), a hook, arithmetic on what autograd.grad(..., inputs=[rast]) hands out.  Whoever
+    looks sees the reference's values; the price is paid by those who look.  (What no dispatch can see: raw `.data_ptr()` access
+    to this object from user code -- it points at a single zero.)"""
+
+    @staticmethod
+    def __new__(cls, like, source, index):
+        key = (like.device, like.dtype)
+        zero = _LazyGrad._zeros.get(key)
+        if zero is None:
+            zero = torch.zeros((), dtype=like.dtype, device=like.device)
+            if not _is_capturing(like.device):           # (memory allocated while a hipGraph is recorded belongs to the graph's pool)
+                _LazyGrad._zeros[key] = zero
+        r = torch.Tensor._make_subclass(cls, zero.expand(like.shape), False)
+        r._source, r._index = source, index
+        # An in-place operation on the stand-in (a hook doing g.mul_(2)) is carried out on the materialised values by
+        # __torch_dispatch__, below the level that counts versions -- the counter that moves is the STAND-IN's (shared by all
+        # stand-ins of this device and dtype: they are views of one zero).  unedited() compares it with what it was here.
+        r._v0 = r._version
+        return r
+
+    def unedited(self):
+        return self._version == self._v0
+
+    def materialize(self):
+        return self._source.get()[self._index]
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        real = lambda t: t.materialize() if isinstance(t, _LazyGrad) else t          # noqa: E731
+        return func(*_tree_map(real, args), **_tree_map(real, kwargs or {}))
+
+
+_LazyGrad._zeros = {}
+
+
+class _LazySource:
+    """Computes the real gradients behind one or two _LazyGrad objects, once, on first use; drops its inputs afterwards.
+    `inputs` are the tensors the thunk reads: autograd's own saved-tensor check ran when the backward node unpacked them, so an
+    in-place change made AFTER that (an optimizer step between autograd.grad(loss, [rast]) and the first look at the result)
+    would go unnoticed -- their version counters are recorded here and compared at materialisation, with autograd's message."""
+    __slots__ = ("thunk", "values", "inputs")
+
+    def __init__(self, thunk, inputs=()):
+        self.thunk, self.values = thunk, None
+        self.inputs = tuple((t, t._version) for t in inputs if t is not None)
+
+    def get(self):
+        if self.values is None:
+            for t, version in self.inputs:
+                if t._version != version:
+                    raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                                       "a tensor read by the deferred gradient of rast is at version %d; expected version %d (the "
+                                       "gradient was requested before the change and first looked at after it)" % (t._version, version))
+            self.values, self.thunk, self.inputs = self.thunk(), None, ()
+            fused_backward_count("materialized")
+        return self.values
+
+
+class _FwdOrigin:
+    """What the record of a `rast` tensor remembers of the rasterize_fwd_cuda call that wrote it (see the section comment)."""
+    __slots__ = ("pos", "pos_version", "tri", "tri_version", "state", "rast_ptr", "rast_version", "rast_shape",
+                 "db_ptr", "db_version", "interpolations", "pending")
+
+    def __init__(self, pos, tri, state, rast, rast_db):
+        self.pos, self.pos_version, self.tri, self.tri_version, self.state = pos, pos._version, tri, tri._version, state
+        self.rast_ptr, self.rast_version, self.rast_shape = rast.data_ptr(), rast._version, tuple(rast.shape)
+        self.db_ptr, self.db_version = rast_db.data_ptr(), rast_db._version
+        self.interpolations = 0            # interpolate_fwd[_da] calls that read this rast
+        self.pending = None                # (weak ref to the g_rast stand-in, g_pos, weak ref to the g_rast_db stand-in or None)
+
+    def is_rast(self, t):
+        return t.data_ptr() == self.rast_ptr and t._version == self.rast_version and tuple(t.shape) == self.rast_shape
+
+    def usable_by(self, attr, rast, tri, rast_db):
+        return (_fused["mode"] == "auto" and self.state.fused_disabled != _fused_epoch[0] and self.interpolations == 1
+                and self.pos.requires_grad and rast.requires_grad and self.is_rast(rast)
+                and self.pos._version == self.pos_version and self.tri._version == self.tri_version
+                and (rast_db is None or (rast_db.data_ptr() == self.db_ptr and rast_db._version == self.db_version))
+                and tri.data_ptr() == self.tri.data_ptr() and tri.shape == self.tri.shape
+                and attr.shape[-2] == self.pos.shape[-2])
+
+
+def _origin_of(rast):
+    rec = _record_of(rast, "rast")
+    return None if rec is None else rec.origin
+
+
+def _fused_interpolate_grad(org, attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_attrs_vec, tile_flags):
+    """interpolate_grad[_da] of a rast straight from rasterize_fwd_cuda: position gradient prepared in the same pass."""
+    g_attr, _, _, g_pos = interpolate_rasterize_grad(attr, rast, tri, org.pos, dy, with_g_rast=False, tile_flags=tile_flags,
+                                                     rast_db=rast_db, dda=dda, diff_attrs_all=diff_attrs_all,
+                                                     diff_attrs_vec=diff_attrs_vec, db_to_pos=True)
+    if rast_db is None:
+        source = _LazySource(lambda: interpolate_grad_da(attr, rast, tri, dy, None, None, False, [], tile_flags, fuse=False)[1:2],
+                             (attr, rast, tri, dy))
+        g_rast, g_rast_db = _LazyGrad(rast, source, 0), None
+    else:
+        source = _LazySource(lambda: interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_attrs_vec, tile_flags,
+                                                         fuse=False)[1:], (attr, rast, tri, dy, rast_db, dda))
+        g_rast, g_rast_db = _LazyGrad(rast, source, 0), _LazyGrad(rast_db, source, 1)
+        g_rast_db._origin = org
+    g_rast._origin = org                   # (the stand-in keeps the exchange alive: `rast` itself may be gone when rasterize's node runs)
+    org.pending = (weakref.ref(g_rast), g_pos, None if g_rast_db is None else weakref.ref(g_rast_db))
+    return g_attr, g_rast, g_rast_db
+
+
+def _take_prepared(fn, pos, tri, out, dy, ddb, call):
+    """rasterize_grad[_db] side of the exchange: the prepared position gradient if (dy, ddb) are what interpolate_grad[_da] handed
+    out, else None (after which the caller materialises any stand-in and computes as usual).  `call(dy, ddb, grad)` launches
+    nvdr_rasterize_grad into an existing gradient buffer."""
+    lazy = isinstance(dy, _LazyGrad)
+    # the stand-in carries the exchange (the caller's `rast` may be gone by now); an ordinary tensor arriving while something is
+    # prepared for this rast -- autograd summed rast's gradient with somebody else's -- voids it
+    org = getattr(dy, "_origin", None) if lazy else _origin_of(out)
+    if org is None or org.pending is None:
+        return None
+    (w_rast, g_pos, w_db), org.pending = org.pending, None
+    lz_rast, lz_db = w_rast(), (None if w_db is None else w_db())
+    ok = (lazy and lz_rast is dy and dy.unedited() and org.is_rast(out)
+          and pos.data_ptr() == org.pos.data_ptr() and pos._version == org.pos_version and pos.shape == org.pos.shape
+          and tri.data_ptr() == org.tri.data_ptr() and tri._version == org.tri_version and tri.shape == org.tri.shape)
+    if ok and w_db is not None:
+        # prepared WITH rast_db's gradient folded in: stands only if that is what arrives for ddb (a caller whose rasterize ran
+        # with grad_db=False calls rasterize_grad: ddb None)
+        ok = ddb is not None and ddb is lz_db and lz_db.unedited()
+    elif ok and ddb is not None:
+        # prepared from dy alone; ddb's share is added now (linearity) -- unless it is a stand-in of some other exchange
+        ok = not isinstance(ddb, _LazyGrad)
+        if ok:
+            call(None, ddb, g_pos)
+    if ok:
+        fused_backward_count("used")
+        return g_pos
+    fused_backward_count("discarded")
+    if org.state.fused_disabled != _fused_epoch[0]:
+        _log_info("fused rasterize/interpolate backward switched off on this context: rast's gradient has other contributors "
+                  "(set_fused_backward('auto') re-arms it)")
+    org.state.fused_disabled = _fused_epoch[0]
+    return None
+
+
 def rasterize_grad_db(pos, tri, out, dy, ddb, tile_flags=None):
-    """torch_rasterize.cpp:171-256.  ``ddb`` may be None (== rasterize_grad)."""
+    """torch_rasterize.cpp:171-256.  ``ddb`` may be None (== rasterize_grad).  ``dy`` may be None as well -- what a caller whose
+    autograd function runs with set_materialize_grads(False) passes for an unused `rast`: only ddb's
+    share is computed; with both None the gradient is zero."""
     fn = "rasterize_grad_db"
     enable_db = ddb is not None
+    given = {"dy": dy} if dy is not None else {}             # the upstream gradients that are there
     if enable_db:
-        dev = _check_device(fn, pos=pos, tri=tri, out=out, dy=dy, ddb=ddb)
-        _check_contiguous(fn, pos=pos, tri=tri, out=out)
-        _check_f32(fn, pos=pos, out=out, dy=dy, ddb=ddb)
-    else:
-        dev = _check_device(fn, pos=pos, tri=tri, out=out, dy=dy)
-        _check_contiguous(fn, pos=pos, tri=tri, out=out)
-        _check_f32(fn, pos=pos, out=out, dy=dy)
+        given["ddb"] = ddb
+    dev = _check_device(fn, pos=pos, tri=tri, out=out, **given)
+    _check_contiguous(fn, pos=pos, tri=tri, out=out)
+    _check_f32(fn, pos=pos, out=out, **given)
     _check_i32(fn, tri=tri)
 
     instance_mode = pos.dim() > 2
@@ -489,21 +659,34 @@ def rasterize_grad_db(pos, tri, out, dy, ddb, tile_flags=None):
         _require(pos.dim() == 2 and pos.size(0) > 0 and pos.size(1) == 4, fn, "pos must have shape [>0, 4]")
     _require(tri.dim() == 2 and tri.size(0) > 0 and tri.size(1) == 3, fn, "tri must have shape [>0, 3]")
     _require(tuple(out.shape) == (depth, height, width, 4), fn, "out must have shape [depth, height, width, 4]")
-    _require(tuple(dy.shape) == (depth, height, width, 4), fn, "dy must have shape [depth, height, width, 4]")
+    if dy is not None:
+        _require(tuple(dy.shape) == (depth, height, width, 4), fn, "dy must have shape [depth, height, width, 4]")
     if enable_db:
         _require(tuple(ddb.shape) == (depth, height, width, 4), fn, "ddb must have shape [depth, height, width, 4]")
 
-    dy_ = dy.contiguous()
-    ddb_ = ddb.contiguous() if enable_db else None
     V = pos.size(1) if instance_mode else pos.size(0)
     tile_flags = _auto_flags(fn, tile_flags, "rast", out)
+
+    def call(dy, ddb, grad):
+        dy_ = None if dy is None else dy.contiguous()
+        ddb_ = None if ddb is None else ddb.contiguous()
+        with _on_device(dev):
+            rc = _capi.load().nvdr_rasterize_grad(pos.data_ptr(), tri.data_ptr(), out.data_ptr(), _capi.ptr(dy_),
+                                                  _capi.ptr(ddb_), int(instance_mode), depth, V, tri.size(0),
+                                                  height, width, grad.data_ptr(), _flags_ok(fn, tile_flags, depth, height, width, dev),
+                                                  _stream(dev))
+        _capi.check(rc, fn)
+
+    # gradients handed out by interpolate_grad[_da] of this module (section "fused backward" above)
+    grad = _take_prepared(fn, pos, tri, out, dy, ddb, call)
+    if grad is not None:
+        return grad
+    dy = dy.materialize() if isinstance(dy, _LazyGrad) else dy
+    ddb = ddb.materialize() if isinstance(ddb, _LazyGrad) else ddb
     with _on_device(dev):
         grad = torch.zeros_like(pos)
-        rc = _capi.load().nvdr_rasterize_grad(pos.data_ptr(), tri.data_ptr(), out.data_ptr(), dy_.data_ptr(),
-                                              _capi.ptr(ddb_), int(instance_mode), depth, V, tri.size(0),
-                                              height, width, grad.data_ptr(), _flags_ok(fn, tile_flags, depth, height, width, dev),
-                                              _stream(dev))
-    _capi.check(rc, fn)
+    if dy is not None or ddb is not None:
+        call(dy, ddb, grad)
     return grad
 
 
@@ -569,6 +752,9 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec,
     D = (A if diff_attrs_all else len(diff_attrs_vec)) if enable_da else 0
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
     tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
+    org = _origin_of(rast)
+    if org is not None:
+        org.interpolations += 1
     with _on_device(dev):
         out = torch.empty((N, H, W, A), dtype=torch.float32, device=dev)
         out_da = torch.empty((N, H, W, 2 * D), dtype=torch.float32, device=dev)
@@ -594,8 +780,9 @@ def interpolate_fwd(attr, rast, tri, tile_flags=None):
     return interpolate_fwd_da(attr, rast, tri, None, False, [], tile_flags)
 
 
-def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_attrs_vec, tile_flags=None):
-    """torch_interpolate.cpp:137-239."""
+def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_attrs_vec, tile_flags=None, fuse=None):
+    """torch_interpolate.cpp:137-239.  `fuse` (not in the reference): None = prepare rasterize_grad's result in the same pass when
+    `rast` came straight from rasterize_fwd_cuda (section "fused backward" above); False = never."""
     fn = "interpolate_grad_da"
     enable_da = (rast_db is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
     instance_mode = attr.dim() > 2
@@ -640,6 +827,13 @@ def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_
     dda_ = dda.contiguous() if enable_da else None
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
     tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
+    if fuse is None and _fused["mode"] == "auto":
+        org = _origin_of(rast)
+        if org is not None:
+            org.pending = None             # left over from a backward pass that never reached rasterize_grad: void
+            if org.usable_by(attr, rast, tri, rast_db if enable_da else None):
+                return _fused_interpolate_grad(org, attr, rast, tri, dy, rast_db if enable_da else None, dda if enable_da else None,
+                                               diff_attrs_all, diff_attrs_vec, tile_flags)
     with _on_device(dev):
         g_attr = torch.zeros_like(attr)
         g_rast = torch.empty_like(rast)
@@ -654,9 +848,9 @@ def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_
     return g_attr, g_rast, g_rast_db
 
 
-def interpolate_grad(attr, rast, tri, dy, tile_flags=None):
+def interpolate_grad(attr, rast, tri, dy, tile_flags=None, fuse=None):
     """torch_interpolate.cpp:242-248."""
-    g_attr, g_rast, _ = interpolate_grad_da(attr, rast, tri, dy, None, None, False, [], tile_flags)
+    g_attr, g_rast, _ = interpolate_grad_da(attr, rast, tri, dy, None, None, False, [], tile_flags, fuse)
     return g_attr, g_rast
 
 

@@ -18,7 +18,6 @@ import weakref
 
 import numpy as np
 import torch
-from torch.utils._pytree import tree_map as _tree_map
 
 from . import _plugin
 
@@ -106,72 +105,7 @@ class _Dispatch(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-class _LazyGrad(torch.Tensor):
-    """The gradient of `rast` (or `rast_db`) that interpolate's backward returns when the fused kernel has already turned it into
-    the position gradient: a tensor whose VALUES are computed only if somebody looks at them.
-
-    In the graph rasterize -> interpolate the only reader of rast's gradient is rasterize's backward, and that one does not need
-    it any more (see _RasterOrigin) -- yet it is 16 B/pixel of stores (268 MB of the 297 MB the fused kernel wrote at the
-    headline batch), zeros for three quarters of them.  So the kernel does not write it, and autograd gets this stand-in: shape,
-    dtype and device of the real thing (a stride-0 view of one zero, so it has storage for the engine's stream bookkeeping), and
-    a __torch_dispatch__ that replaces it by the real gradient -- computed then by the reference's own two-kernel formulation,
-    interpolate_grad[_da] -- in front of ANY operation that touches it: autograd's summation when rast's gradient has other
-    contributors, the clone of retain_grad(), a hook, arithmetic on what autograd.grad(..., inputs=[rast]) hands out.  Whoever
-    looks sees the reference's values; the price is paid by those who look.  (What no dispatch can see: raw `.data_ptr()` access
-    to this object from user code -- it points at a single zero.)"""
-
-    @staticmethod
-    def __new__(cls, like, source, index):
-        key = (like.device, like.dtype)
-        zero = _LazyGrad._zeros.get(key)
-        if zero is None:
-            zero = torch.zeros((), dtype=like.dtype, device=like.device)
-            if not _plugin._is_capturing(like.device):           # (memory allocated while a hipGraph is recorded belongs to the graph's pool)
-                _LazyGrad._zeros[key] = zero
-        r = torch.Tensor._make_subclass(cls, zero.expand(like.shape), False)
-        r._source, r._index = source, index
-        # An in-place operation on the stand-in (a hook doing g.mul_(2)) is carried out on the materialised values by
-        # __torch_dispatch__, below the level that counts versions -- the counter that moves is the STAND-IN's (shared by all
-        # stand-ins of this device and dtype: they are views of one zero).  unedited() compares it with what it was here.
-        r._v0 = r._version
-        return r
-
-    def unedited(self):
-        return self._version == self._v0
-
-    def materialize(self):
-        return self._source.get()[self._index]
-
-    @classmethod
-    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
-        real = lambda t: t.materialize() if isinstance(t, _LazyGrad) else t          # noqa: E731
-        return func(*_tree_map(real, args), **_tree_map(real, kwargs or {}))
-
-
-_LazyGrad._zeros = {}
-
-
-class _LazySource:
-    """Computes the real gradients behind one or two _LazyGrad objects, once, on first use; drops its inputs afterwards.
-    `inputs` are the tensors the thunk reads: autograd's own saved-tensor check ran when the backward node unpacked them, so an
-    in-place change made AFTER that (an optimizer step between autograd.grad(loss, [rast]) and the first look at the result)
-    would go unnoticed -- their version counters are recorded here and compared at materialisation, with autograd's message."""
-    __slots__ = ("thunk", "values", "inputs")
-
-    def __init__(self, thunk, inputs=()):
-        self.thunk, self.values = thunk, None
-        self.inputs = tuple((t, t._version) for t in inputs if t is not None)
-
-    def get(self):
-        if self.values is None:
-            for t, version in self.inputs:
-                if t._version != version:
-                    raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
-                                       "a tensor read by the deferred gradient of rast is at version %d; expected version %d (the "
-                                       "gradient was requested before the change and first looked at after it)" % (t._version, version))
-            self.values, self.thunk, self.inputs = self.thunk(), None, ()
-            _plugin.fused_backward_count("materialized")
-        return self.values
+_LazyGrad, _LazySource = _plugin._LazyGrad, _plugin._LazySource     # (the stand-in for a gradient nobody may look at: _plugin.py)
 
 
 class _RasterOrigin:
@@ -337,11 +271,11 @@ class _InterpolateOp:
         if origin is not None and origin.usable_by(attr, rast, tri):
             g_attr, _, _, g_pos = _plugin.interpolate_rasterize_grad(attr, rast, tri, origin.pos, d_out, with_g_rast=False, tile_flags=flags)
             # g_rast itself is not written: autograd gets a stand-in that computes it if anybody looks (_LazyGrad)
-            source = _LazySource(lambda: (_plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)[1],), (attr, rast, tri, d_out))
+            source = _LazySource(lambda: (_plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags, fuse=False)[1],), (attr, rast, tri, d_out))
             g_rast = _LazyGrad(rast, source, 0)
             origin.pending = (weakref.ref(g_rast), g_pos, None)
             return g_attr, g_rast
-        return _plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags)
+        return _plugin.interpolate_grad(attr, rast, tri, d_out, tile_flags=flags, fuse=False)
 
     @staticmethod
     def backward(state, saved, d_out, d_out_da):
@@ -363,12 +297,12 @@ class _InterpolateOp:
                     attr, rast, tri, origin.pos, d_out, with_g_rast=False, tile_flags=flags, rast_db=rast_db, dda=d_out_da,
                     diff_attrs_all=diff_all, diff_attrs_vec=diff_list, db_to_pos=origin.grad_db)
                 source = _LazySource(lambda: _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
-                                                                         tile_flags=flags)[1:], (attr, rast, tri, d_out, rast_db, d_out_da))
+                                                                         tile_flags=flags, fuse=False)[1:], (attr, rast, tri, d_out, rast_db, d_out_da))
                 g_rast, g_rast_db = _LazyGrad(rast, source, 0), _LazyGrad(rast_db, source, 1)
                 origin.pending = (weakref.ref(g_rast), g_pos, weakref.ref(g_rast_db))
                 return g_attr, g_rast, None, g_rast_db, None, None
             g_attr, g_rast, g_rast_db = _plugin.interpolate_grad_da(attr, rast, tri, d_out, rast_db, d_out_da, diff_all, diff_list,
-                                                                    tile_flags=flags)
+                                                                    tile_flags=flags, fuse=False)
             return g_attr, g_rast, None, g_rast_db, None, None
         attr, rast, tri = saved
         g_attr, g_rast = _InterpolateOp._plain_grad(attr, rast, tri, d_out, origin)

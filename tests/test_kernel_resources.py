@@ -61,8 +61,10 @@ def test_rasterizer_kernels_stay_within_their_budgets(tmp_path):
     for name, v in k.items():                                                   # depth peeling / depth surface: every instantiation at 8 waves/SIMD
         if re.search(r"k_fineILb[01]ELb[01]ELb0E", name):                         # (all but the debug instantiations)
             assert v[1] <= 64 and v[0] <= 16, (name, v)
-    grad = k["_ZN4nvdr13k_raster_gradILb0EEEvNS_10GradParamsEii"]
+    grad = k["_ZN4nvdr13k_raster_gradILb0ELb0EEEvNS_10GradParamsEii"]
     assert grad[0] == 0 and grad[1] <= 80, grad                                 # 6 waves/SIMD
+    db_only = k["_ZN4nvdr13k_raster_gradILb1ELb1EEEvNS_10GradParamsEii"]          # rast_db's share alone (dy == NULL): the plugin-level fused backward
+    assert db_only[0] == 0 and db_only[1] <= 128, db_only
     setup = k["_ZN4nvdr7k_setupENS_11SetupParamsEi"]
     assert setup[1] <= 102, setup                                               # 5 workgroups/CU (its scratch belongs to the clipper's rare path)
 
