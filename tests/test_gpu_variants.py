@@ -40,7 +40,8 @@ def test_gpu_suite_with_tile_flag_verification():
     and fails on a mismatch (legality rests on pointer / version / shape; this run checks the claim itself)."""
     env = dict(os.environ, NVDR_VERIFY_TILE_FLAGS="1")
     files = ["test_gpu_tile_flags.py", "test_gpu_raster_interp.py", "test_gpu_texture_aa.py", "test_gpu_fused_backward.py",
-             "test_gpu_end_to_end.py", "test_gpu_edge_cases.py", "test_gpu_reference_ops.py"]      # (the last: the reference's own call lists, ADVICE r4)
+             "test_gpu_end_to_end.py", "test_gpu_edge_cases.py", "test_gpu_reference_ops.py",       # (the reference's own call lists, ADVICE r4)
+             "test_gpu_plugin_fused_backward.py"]                                                  # (flags found by the plugin itself, inside autograd)
     r = subprocess.run([sys.executable, "-m", "pytest"] + [os.path.join(ROOT, "tests", f) for f in files] +
                        ["-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
