@@ -353,6 +353,8 @@ class Job:
         self.shared.grad = None
         if self.full:
             self.tex.grad = None
+        self.last_rast = None             # (kept for coverage() after the LAST step only: a training loop does not hold the previous step's rast
+        #                                   while it renders the next; holding it cost 17 us per headline step, profiles/r05q_keep_rast_ab.log)
         # gather_every = k: the consumer of the complete batch of images (a logger, a discriminator on another rank ...) wants
         # it every k-th step only; that step's all-gather then has k steps' worth of kernels to hide behind -- it is waited for
         # when its receive buffers are needed again, k steps later (or at the end of the timed window)
@@ -427,30 +429,41 @@ class Job:
 
     # ---- everything below runs on rank 0 after the timed region -----------------------------------------------------
 
+    def _measure_coverage(self):
+        """Both coverage figures of the last step's rast, once; the tensor is let go afterwards (a 268 MB block that stays
+        allocated moves every later allocation: the kernels' times depend on where their tensors lie, see profile_kernels)."""
+        if self.last_rast is not None:
+            c = (self.last_rast[..., 3] > 0).float()
+            self._coverage = (round(float(c.mean().item()), 4),
+                              round(float(torch.nn.functional.max_pool2d(c[:, None], 8, ceil_mode=True).mean().item()), 4))
+            self.last_rast = None
+        return getattr(self, "_coverage", (None, None))
+
     def coverage(self):
         """Fraction of the pixels of the last step that a triangle covers (kernels may skip upstream gradients elsewhere)."""
-        if self.last_rast is None:
-            return None
-        return round(float((self.last_rast[..., 3] > 0).float().mean().item()), 4)
+        return self._measure_coverage()[0]
 
     def tile_coverage(self):
         """Fraction of the 8x8-pixel tiles of the last step with a covered pixel: what the consumers of rast cannot skip."""
-        if self.last_rast is None:
-            return None
-        c = (self.last_rast[..., 3] > 0).float()
-        return round(float(torch.nn.functional.max_pool2d(c[:, None], 8, ceil_mode=True).mean().item()), 4)
+        return self._measure_coverage()[1]
 
     def profile_kernels(self, prof_steps, ms_per_step):
         """Per-kernel hipEvent timing inside the library (one chunk per launch) -> (kernels, roofline, path_frac)."""
         lib, _capi = self.lib, self._capi
+        self._measure_coverage()                         # (... and lets the timed loop's last rast go)
         lib.nvdr_profile_reset()
         lib.nvdr_profile_enable(1)
         for _ in range(prof_steps):
+            # the same allocation pattern as step(): nothing of the previous iteration alive when the next one allocates.  The
+            # caching allocator then hands every tensor the block it had the step before; with one more 268 MB block in
+            # circulation (a rast or an image held across iterations) interpolate's forward kernel runs 74 instead of 56 us on
+            # the same inputs (profiles/r05q_keep_rast_ab.log).
             self.pos.grad = None; self.shared.grad = None
             if self.full:
                 self.tex.grad = None
             out, _ = self.render(self.pos)
             torch.autograd.backward(out, self.G)
+            del out, _
         torch.cuda.synchronize()
         prof = _capi.profile_read()
         lib.nvdr_profile_enable(0)
