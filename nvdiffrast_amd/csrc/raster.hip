@@ -1062,6 +1062,7 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
     // (A threshold that follows the batch -- sixteen while few masks exceed eight fragments -- was measured in round 5: within 1 %
     // on every scene; a fixed 12..16 is 2-3 % faster on meshes of small triangles and 3-5 % slower on the stress scene.)
     constexpr int kCoop = 8;
+    constexpr int kOctMin = 5;                               // big masks in a batch from which they are taken eight at a time
     const bool big = __popcll(m) > kCoop;
     uint64_t heavy = __ballot(big);
     const int kBig = heavy ? 2 : 0;
@@ -1092,7 +1093,42 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
     if (heavy && !(DBG && (p.dbg & 4096))) {
         const uint32_t xl = (uint32_t)(lane & 7), yl = (uint32_t)(lane >> 3);                 // this lane's pixel: bit `lane` of a mask
         unsigned long long* keys0 = &sh.key[0][0][0];
-        do {
+        // A batch with many big masks (the stress scenes: triangles of tens of pixels, several deep) takes them EIGHT at a time:
+        // eight lanes per mask, lane k of a group walking column k of that mask's tile downwards.  The operands of a group come
+        // from seven ds_bpermute (per eight masks) instead of seven v_readlane per mask, and a step is an add, a bit test and the
+        // LDS minimum (the key's address is the column's plus a constant): ~12 instead of ~20 vector instructions per mask.  The
+        // minima of a step touch eight tiles, 512 B apart: two lanes per bank pair per pass, hidden behind the vector work
+        // (NOTES 9.9).  Not while peeling (a step would need the previous layer's depth from memory).
+        if (!PEEL) {
+            while (__popcll(heavy) >= kOctMin) {
+                int srcLane = -1;                                                             // this group's mask is that lane's
+#pragma unroll
+                for (int g = 0; g < 8; g++) {
+                    const int sl = heavy ? (int)__builtin_ctzll(heavy) : -1;
+                    heavy &= heavy - 1;                                                       // (0 stays 0)
+                    if (__builtin_amdgcn_inverse_ballot_w64(0xFFull << (8 * g))) srcLane = sl;
+                }
+                const int a4 = srcLane << 2;
+                uint32_t smlo = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)m0lo), smhi = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)m0hi);
+                const uint32_t szx = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)zx), szy = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)zy);
+                const uint32_t sd0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)d0), sidk = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)idk);
+                const int stile = __builtin_amdgcn_ds_bpermute(a4, tile);
+                if (srcLane < 0) { smlo = 0u; smhi = 0u; }                                    // fewer than eight left: idle groups
+                if (ezOn && xl == 0u && (smlo & smhi) == 0xFFFFFFFFu) {                       // full tile: its bound at once (as below)
+                    const uint32_t cmax = sd0 + 7u * (uint32_t)max((int)szx, 0) + 7u * (uint32_t)max((int)szy, 0);
+                    atomicMin(&sh.tileZ[stile], (cmax >> 16) + 1u);
+                }
+                const uint32_t wlo = smlo >> xl, whi = smhi >> xl;                            // column xl: bit 8 * (y & 3) of the half that holds row y
+                uint32_t depth = sd0 + szx * xl;                                              // (U32 wrap, as the 24-bit pieces give it)
+                unsigned long long* kp = keys0 + stile * 64 + (int)xl;
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    if ((y < 4 ? wlo : whi) & (1u << (8 * (y & 3)))) atomicMin(&kp[y * 8], ((unsigned long long)depth << 32) | sidk);
+                    depth += szy;
+                }
+            }
+        }
+        if (heavy) do {
             const int src = __builtin_ctzll(heavy);
             heavy &= heavy - 1;
             const uint64_t sm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)m0hi, src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)m0lo, src);
