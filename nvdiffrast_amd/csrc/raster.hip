@@ -25,7 +25,8 @@
 //            by a prefix sum and dealt to the waves 64 at a time, ONE LANE PER PAIR: the lane
 //            walks its triangle's three edge functions over the tile's 64 pixel centres with
 //            integer adds (two pixels per instruction, in 16-bit halves) into a 64-bit coverage mask, then pops the set bits (masks with many
-//            fragments: the whole wave, one lane per pixel, the mask as execution mask) and merges
+//            fragments: eight masks at a time, eight lanes per mask, when the batch holds several; else the whole wave,
+//            one lane per pixel, the mask as execution mask) and merges
 //            depth << 32 | ~id into the tile's per-pixel keys with an LDS 64-bit atomic min:
 //            minimum depth wins, ties go to the highest triangle id, which is exactly what
 //            the reference's in-order LEQUAL ROP produces (FineRaster.inl:152-172,349-361)
@@ -1057,8 +1058,9 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
     // Fragments.  Triangles are small: a wave's 64 masks hold 4 fragments on average but 28 at the maximum
     // (measured on the headline batch), so letting every lane pop its own bits keeps 63 lanes waiting for the
     // fullest one.  Masks above kCoop fragments are therefore rasterised by the WHOLE wave, one lane per pixel
-    // (the mask is the execution mask: no bit scanning, one conflict-free LDS atomic per mask); the others are
-    // popped by their own lanes, at most kCoop rounds.
+    // (the mask is the execution mask: no bit scanning, one conflict-free LDS atomic per mask) -- or, when the batch holds
+    // kOctMin of them or more, eight masks at a time by eight lanes each (below); the others are popped by their own
+    // lanes, at most kCoop rounds.
     // (A threshold that follows the batch -- sixteen while few masks exceed eight fragments -- was measured in round 5: within 1 %
     // on every scene; a fixed 12..16 is 2-3 % faster on meshes of small triangles and 3-5 % slower on the stress scene.)
     constexpr int kCoop = 8;
