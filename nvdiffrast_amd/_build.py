@@ -53,6 +53,7 @@ def build(force=False, verbose=False):
     """One object per source file, compiled in parallel (each .hip is a self-contained translation unit: no relocatable
     device code), then linked; objects of unchanged sources are reused unless a header changed or `force` is set."""
     if not force and not is_stale():
+        _build_host_layers(False, verbose)
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     hipcc = find_hipcc()
@@ -78,8 +79,19 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    build_ffi(force=force, verbose=verbose)
+    _build_host_layers(force, verbose)
     return LIB_PATH
+
+
+def _build_host_layers(force, verbose):
+    """The two compiled host layers are optional at run time (_capi falls back to ctypes, ops.py to _plugin): a box without gcc
+    or the Python / torch headers still gets the library it has just built.  An explicit build_ffi() / build_host() raises."""
+    for step in (build_ffi, build_host):
+        try:
+            step(force=force, verbose=verbose)
+        except Exception as e:                                                  # noqa: BLE001
+            import warnings
+            warnings.warn("nvdiffrast_amd: %s failed (%s); the package runs without it" % (step.__name__, e))
 
 
 FFI_SRC = os.path.join(_HERE, "csrc_host", "nvdr_ffi.c")
@@ -101,7 +113,39 @@ def build_ffi(force=False, verbose=False):
     return FFI_PATH
 
 
+HOST_SRC = os.path.join(_HERE, "csrc_host", "nvdr_torch_host.cpp")
+HOST_PATH = os.path.join(_HERE, "_nvdr_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """The compiled host layer of rasterize / interpolate (csrc_host/nvdr_torch_host.cpp): HOST code only, plain g++ against
+    torch's headers -- no device code, nothing goes through torch's hipify build path.  The kernels are reached through the
+    C ABI, whose addresses the module receives at run time."""
+    deps = [HOST_SRC, os.path.join(_HERE, "..", "include", "nvdr_hip.h")]
+    if not force and os.path.exists(HOST_PATH) and os.path.getmtime(HOST_PATH) > max(os.path.getmtime(d) for d in deps):
+        return HOST_PATH
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("g++ not found; cannot build _nvdr_host.so (the package falls back to the Python host layer without it)")
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_nvdr_host", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    cmd += ["-I" + p for p in cpp_extension.include_paths()] + ["-I" + os.path.join(rocm, "include"), "-I" + sysconfig.get_paths()["include"]]
+    cmd += [HOST_SRC, "-o", HOST_PATH, "-L" + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", "-lamdhip64",
+            "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_PATH
+
+
 if __name__ == "__main__":
     build_ffi(force=True, verbose=True)
+    build_host(force=True, verbose=True)
     build(force=True, verbose=True)
     print(LIB_PATH)

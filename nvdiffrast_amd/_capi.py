@@ -139,6 +139,34 @@ def _compiled_binding(cdll):
     return _BoundLib(cdll, bound)
 
 
+_host = None
+_host_tried = False
+_HOST_SYMBOLS = ("nvdr_last_error", "nvdr_get_option", "nvdr_log", "nvdr_rasterize_scratch_bytes_pool", "nvdr_rasterize_pool_peak_offset",
+                 "nvdr_tile_flags_bytes", "nvdr_rasterize_fwd", "nvdr_rasterize_grad", "nvdr_interpolate_fwd", "nvdr_interpolate_grad",
+                 "nvdr_interpolate_rasterize_grad")
+
+
+def host():
+    """The compiled host layer of rasterize / interpolate (csrc_host/nvdr_torch_host.cpp: validation, allocation, launch and the
+    autograd nodes in C++), bound to the entry points of THIS library instance -- or None: NVDR_HOST=0, or the module has not
+    been built (the Python host layer, torch/_plugin.py, then serves every call)."""
+    global _host, _host_tried
+    if _host_tried:
+        return _host
+    _host_tried = True
+    if os.environ.get("NVDR_HOST", "1") in ("0", ""):
+        return None
+    try:
+        import torch  # noqa: F401  (the module links against libtorch)
+        from . import _nvdr_host
+    except ImportError:
+        return None
+    cdll = load()._cdll
+    _nvdr_host.init({name: ctypes.cast(getattr(cdll, name), c_void_p).value for name in _HOST_SYMBOLS})
+    _host = _nvdr_host
+    return _host
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().nvdr_last_error().decode("utf-8", "replace")

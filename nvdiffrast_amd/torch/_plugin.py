@@ -49,6 +49,8 @@ def set_fused_backward(mode):
     _fused["mode"] = mode
     if mode == "auto":
         _fused_epoch[0] += 1
+    if _host_state["mod"]:
+        _host_state["mod"].set_fused(mode == "auto")
 
 
 def fused_backward_mode():
@@ -68,8 +70,45 @@ def fused_backward_count(what=None):
     """Counts how often a prepared position gradient was used / discarded, and how often the gradient of rast that the fused
     kernel did not write had to be computed after all (tests); without argument returns all three."""
     if what is None:
-        return {"used": _fused["used"], "discarded": _fused["discarded"], "materialized": _fused["materialized"]}
+        r = {"used": _fused["used"], "discarded": _fused["discarded"], "materialized": _fused["materialized"]}
+        if _host_state["mod"]:
+            # the compiled layer never discards: what other consumers of rast contribute is ADDED to the prepared share
+            # ("fused_plus"; rasterize_grad is linear in dy) -- both of its outcomes count as used
+            c = _host_state["mod"].counters()
+            r["used"] += c["fused_alone"] + c["fused_plus"]
+            r.update(c)
+        return r
     _fused[what] += 1
+
+
+# ---- the compiled host layer ------------------------------------------------------------------------------------------------
+# csrc_host/nvdr_torch_host.cpp does for rasterize() and interpolate() what this module does -- validation, allocation, launch --
+# and carries their autograd nodes, in C++ (the reference's glue is C++ too: csrc/torch/torch_rasterize.cpp, torch_interpolate.cpp).
+# ops.py asks it first; it declines (None) anything but the ordinary case, and the call then comes here: this module stays the
+# path of the rare modes and of every error message.  NVDR_HOST=0, set_host_layer("python") or an unbuilt module: all calls come here.
+_host_state = {"mod": False, "enabled": True}
+
+
+def host_layer():
+    """The compiled host module, or None."""
+    m = _host_state["mod"]
+    if m is False:
+        m = _host_state["mod"] = _capi.host()
+        if m is not None:
+            m.set_fused(_fused["mode"] == "auto")
+            m.set_skip(_tiles["skip"])
+            m.set_verify(_tiles["verify"])
+    return m if _host_state["enabled"] else None
+
+
+def set_host_layer(mode):
+    """Not in the reference.  "compiled" (default where the module is built) or "python"."""
+    assert mode in ("compiled", "python")
+    _host_state["enabled"] = mode == "compiled"
+
+
+def host_layer_name():
+    return "compiled" if host_layer() is not None else "python"
 
 
 def _is_capturing(device):
@@ -191,6 +230,12 @@ class RasterizeCRStateWrapper:
         self.last_flags = None   # tile occupancy of the most recent rasterize_fwd_cuda output (ops.py attaches it to that rast)
         self.depth = None        # current depth surface  [N,Hp,Wp] int32 (u32 bits)
         self.peel = None         # previous layer's depth surface
+        self._host = None        # the compiled host layer's state of this context (its own scratch and depth surfaces)
+
+    def host_state(self, host):
+        if self._host is None:
+            self._host = host.RasterState(self.cuda_device_idx)
+        return self._host
 
     def get_scratch(self, nbytes, device, layout):
         """Returns (buffer, clean): `clean` tells the library that the buffer's control block is as this
@@ -358,12 +403,16 @@ def set_tile_skipping(enable):
     """Not in the reference.  True (default): kernels that read a rast / rast_db / uv / uv_da tensor skip the 8x8 tiles the
     rasterizer found empty while the tensor is untouched (version counter).  False: every pixel is read, as in the reference."""
     _tiles["skip"] = bool(enable)
+    if _host_state["mod"]:
+        _host_state["mod"].set_skip(bool(enable))
 
 
 def set_tile_flag_verification(enable):
     """Not in the reference.  Debug mode: before every use of tile flags, recompute them from the tensor that was passed (one
     host synchronisation per use) and raise RuntimeError if a tile flagged empty is not.  Also: NVDR_VERIFY_TILE_FLAGS=1."""
     _tiles["verify"] = bool(enable)
+    if _host_state["mod"]:
+        _host_state["mod"].set_verify(bool(enable))        # (the checking mode is served by this module)
 
 
 def tile_flag_verifications():
@@ -383,6 +432,9 @@ class _TileRecord:
         return t.data_ptr() == self.ptr and t._version == self.version and (tuple(t.shape), t.stride()) == self.shape
 
 
+_KIND = {"rast": 0, "zero": 1}
+
+
 def _attach_tiles(t, flags, kind):
     t._nvdr_tiles = _TileRecord(flags, t, kind)
     ptr = t.data_ptr()
@@ -391,6 +443,9 @@ def _attach_tiles(t, flags, kind):
         if _tile_registry.get(ptr) is _ref:
             del _tile_registry[ptr]
     _tile_registry[ptr] = weakref.ref(t, _forget)
+    h = host_layer()
+    if h is not None:
+        h.attach(t, flags, _KIND[kind])          # the compiled layer's registry (by storage): its interpolate() finds the flags too
 
 
 def _record_of(t, kind):
@@ -405,6 +460,16 @@ def _record_of(t, kind):
     if rec is None or rec.kind != kind or not rec.still(t):
         return None
     return rec
+
+
+def flags_of(t, kind="rast"):
+    """The tile flags that are known to describe `t` as it is now -- from the record on the tensor (this module) or from the
+    compiled layer's registry -- or None."""
+    rec = _record_of(t, kind)
+    if rec is not None:
+        return rec.flags
+    h = host_layer()
+    return None if h is None else h.flags_of(t, _KIND[kind])
 
 
 def _verify_tiles(fn, t, flags, kind):
@@ -428,10 +493,10 @@ def _auto_flags(fn, tile_flags, kind, *tensors):
         return None
     if tile_flags is None:
         for t in tensors:
-            rec = _record_of(t, kind)
-            if rec is None or (tile_flags is not None and rec.flags is not tile_flags):
+            f = flags_of(t, kind)
+            if f is None or (tile_flags is not None and f.data_ptr() != tile_flags.data_ptr()):
                 return None
-            tile_flags = rec.flags
+            tile_flags = f
     if tile_flags is not None and _tiles["verify"]:
         for t in tensors:
             _verify_tiles(fn, t, tile_flags, kind)

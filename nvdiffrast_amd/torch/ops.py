@@ -173,10 +173,23 @@ class _ZeroTiles:
         return getattr(uv, "_nvdr_zero_tiles", None), zd
 
     @staticmethod
+    def from_registry(uv, uv_da):
+        """The same answer from the records kept by storage (interpolate() served by the compiled host layer leaves no
+        attribute on its outputs): _plugin.flags_of."""
+        f = _plugin.flags_of(uv, "zero")
+        if f is not None and uv_da is not None and uv_da.numel():
+            fd = _plugin.flags_of(uv_da, "zero")
+            if fd is None or fd.data_ptr() != f.data_ptr():
+                return None
+        return f
+
+    @staticmethod
     def of(uv, uv_da):
         """The flags that texture(uv, uv_da) may use: both tensors (uv_da may be absent) zero on the same empty tiles."""
         z = getattr(uv, "_nvdr_zero_tiles", None)
-        if z is None or uv.data_ptr() != z.ptr or uv._version != z.version or tuple(uv.shape[:3]) != z.shape:
+        if z is None:
+            return _ZeroTiles.from_registry(uv, uv_da)
+        if uv.data_ptr() != z.ptr or uv._version != z.version or tuple(uv.shape[:3]) != z.shape:
             return None
         if uv_da is not None and uv_da.numel():
             zd = getattr(uv_da, "_nvdr_zero_tiles", None)
@@ -319,6 +332,8 @@ class _TextureOp:
         f = _FILTER_MODES[filter_mode]
         zf = None if boundary == _BOUNDARY_MODES["cube"] else _ZeroTiles.of(uv, uv_da)      # tiles of known-zero uv / uv_da
         zrec = _ZeroTiles.records(uv, uv_da) if zf is not None else None
+        if zrec is not None and zrec[0] is None:
+            zrec = None                                      # (flags from the registry: the backward pass asks it again)
         if filter_mode in _MIPMAPPED:
             # absent optional tensors travel as empty tensors, an absent wrapper as an empty one (ops.py:301-307)
             placeholder = torch.tensor([])
@@ -337,8 +352,12 @@ class _TextureOp:
         filter_mode, f, boundary, mip_wrapper, n_custom, zf, zrec = state
         g_uv = g_uv_da = g_bias = None
         g_levels = (None,) * n_custom
-        if zf is not None and not (zrec[0].still(saved[1])
-                                   and (zrec[1] is None or filter_mode not in _MIPMAPPED or zrec[1].still(saved[2]))):
+        if zf is not None and zrec is None:
+            now = _ZeroTiles.from_registry(saved[1], saved[2] if filter_mode in _MIPMAPPED else None)
+            if now is None or now.data_ptr() != zf.data_ptr():
+                zf = None                                     # uv / uv_da were written to since the forward pass
+        elif zf is not None and not (zrec[0].still(saved[1])
+                                     and (zrec[1] is None or filter_mode not in _MIPMAPPED or zrec[1].still(saved[2]))):
             zf = None                                         # uv / uv_da were written to since the forward pass
         if filter_mode in _MIPMAPPED:
             tex, uv, uv_da, bias = saved[:4]
@@ -444,7 +463,19 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     resolution, ranges = _raster_request(glctx, pos, tri, resolution, ranges, grad_db)
     if glctx.active_depth_peeler is not None:
         return RuntimeError("Cannot call rasterize() during depth peeling operation, use rasterize_next_layer() instead")
-    return _Dispatch.apply(_RasterizeOp, glctx, pos, tri, resolution, ranges, grad_db, -1)
+    return _rasterize_layer(glctx, pos, tri, resolution, ranges, grad_db, -1)
+
+
+def _rasterize_layer(glctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
+    """One rasterizer pass: the compiled host layer (csrc_host/nvdr_torch_host.cpp: validation, allocation, launch and the
+    autograd node in C++) when it is there and takes the call, else the Python one (_plugin: rare modes, every error message)."""
+    host = _plugin.host_layer()
+    if host is not None and len(resolution) == 2:
+        served = host.rasterize(glctx.cpp_wrapper.host_state(host), pos, tri, int(resolution[0]), int(resolution[1]), ranges,
+                                grad_db, peeling_idx)
+        if served is not None:
+            return served
+    return _Dispatch.apply(_RasterizeOp, glctx, pos, tri, resolution, ranges, grad_db, peeling_idx)
 
 
 class DepthPeeler:
@@ -486,7 +517,7 @@ class DepthPeeler:
         assert self.peeling_idx >= 0
         layer = self.peeling_idx
         self.peeling_idx += 1
-        return _Dispatch.apply(_RasterizeOp, self.raster_ctx, self.pos, self.tri, self.resolution, self.ranges, self.grad_db, layer)
+        return _rasterize_layer(self.raster_ctx, self.pos, self.tri, self.resolution, self.ranges, self.grad_db, layer)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -518,8 +549,15 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
         assert len(arr.shape) == 1
         selected = arr.tolist()
     _tensors(attr=attr, rast=rast, tri=tri)
-    if want_all or selected:
+    with_da = bool(want_all or selected)
+    if with_da:
         _tensors(rast_db=rast_db)
+    host = _plugin.host_layer()
+    if host is not None:                                    # (see _rasterize_layer)
+        served = host.interpolate(attr, rast, tri, rast_db if with_da else None, want_all, selected)
+        if served is not None:
+            return served
+    if with_da:
         return _Dispatch.apply(_InterpolateOp, attr, rast, tri, rast_db, int(want_all), selected)
     return _Dispatch.apply(_InterpolateOp, attr, rast, tri, None, 0, [])
 

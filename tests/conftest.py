@@ -28,6 +28,15 @@ def ref():
     return _ref
 
 
+@pytest.fixture()
+def python_host_layer():
+    """The Python host layer (torch/_plugin.py) serves every call of the test, as where csrc_host/nvdr_torch_host.cpp is not built."""
+    from nvdiffrast_amd.torch import _plugin
+    _plugin.set_host_layer("python")
+    yield
+    _plugin.set_host_layer("compiled")
+
+
 @pytest.fixture(scope="session")
 def raw_oracle():
     """The C oracle without the reference cross-check."""

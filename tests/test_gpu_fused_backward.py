@@ -10,7 +10,9 @@ from conftest import ATOL, grad_tol, within
 
 from nvdiffrast_amd.utils import m10k_batch
 
-pytestmark = pytest.mark.gpu
+# These tests look INSIDE the Python host layer (the records on the tensors, the stand-in gradient, the discard rule): they run
+# with that layer serving every call.  tests/test_gpu_host_layer.py asks the same questions of the compiled layer.
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("python_host_layer")]
 
 
 def _t(a, dev="cuda"):

@@ -1,0 +1,265 @@
+"""The compiled host layer (csrc_host/nvdr_torch_host.cpp) on the GPU: it is what serves rasterize() / interpolate() by default,
+its results are the Python layer's (same kernels) and the oracle's, and its way of fusing the backward pass -- interpolate's
+backward leaves its share of the position gradient with the rasterize node, other consumers of rast are ADDED on top -- gives
+the reference's gradients in every autograd situation the Python layer's stand-in gradient was built for.
+tests/test_host_layer_logic.py asks the same questions on the CPU against a stub of the C ABI."""
+import numpy as np
+import pytest
+import torch
+from conftest import ATOL, grad_tol, within
+
+from nvdiffrast_amd import _capi
+from nvdiffrast_amd.torch import _plugin
+from nvdiffrast_amd.utils import m10k_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda").requires_grad_(grad)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _scene(n=3, seed=3, res=(120, 136)):
+    b = m10k_batch(n, seed=seed, nx=14, ny=9)
+    G = np.random.default_rng(seed).normal(size=(n,) + res + (b["attr"].shape[-1],)).astype(np.float32)
+    return b, res, G
+
+
+def _chain(oracle, b, res, G, extra=None):
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    oo, _ = oracle.interpolate(b["attr"], ro, b["tri"])
+    ga, gr, _ = oracle.interpolate_grad(b["attr"], ro, b["tri"], G)
+    gp = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr if extra is None else gr + extra)
+    return ro, rdbo, oo, ga, gr, gp
+
+
+def test_the_compiled_layer_is_built_loaded_and_the_default(dr):
+    assert _capi.host() is not None, "nvdiffrast_amd/_nvdr_host.so is missing on the GPU box (python -m nvdiffrast_amd._build)"
+    assert _plugin.host_layer_name() == "compiled"
+    b, res, G = _scene()
+    ctx = dr.RasterizeCudaContext()
+    pos, attr, tri = _t(b["pos"], True), _t(b["attr"], True), _t(b["tri"])
+    rast, _ = dr.rasterize(ctx, pos, tri, res)
+    out, _ = dr.interpolate(attr, rast, tri)
+    assert rast.grad_fn.name() == "NvdrRasterizeBackward" and out.grad_fn.name() == "NvdrInterpolateBackward"
+
+
+def test_same_results_as_the_python_layer_and_the_oracle(dr, oracle):
+    b, res, G = _scene(seed=5)
+    ro, rdbo, oo, ga, gr, gp = _chain(oracle, b, res, G)
+    got = {}
+    for layer in ("compiled", "python"):
+        _plugin.set_host_layer(layer)
+        try:
+            ctx = dr.RasterizeCudaContext()
+            pos, attr, tri = _t(b["pos"], True), _t(b["attr"], True), _t(b["tri"])
+            c0 = _plugin.fused_backward_count()
+            rast, rast_db = dr.rasterize(ctx, pos, tri, res)
+            out, _ = dr.interpolate(attr, rast, tri)
+            torch.autograd.backward(out, _t(G))
+            assert _plugin.fused_backward_count()["used"] == c0["used"] + 1
+            got[layer] = [_np(x) for x in (rast, rast_db, out, attr.grad, pos.grad)]
+        finally:
+            _plugin.set_host_layer("compiled")
+    for a, p in zip(got["compiled"][:3], got["python"][:3]):
+        assert np.array_equal(a, p)                                      # the same kernels on the same inputs
+    r, rdb, o, g_attr, g_pos = got["compiled"]
+    assert (r[..., 3] != ro[..., 3]).sum() == 0
+    within("host layer: rast", r[..., :3], ro[..., :3], ATOL); within("host layer: rast_db", rdb, rdbo, grad_tol(rdbo))
+    within("host layer: out", o, oo, ATOL)
+    within("host layer: g_attr", g_attr, ga, grad_tol(ga)); within("host layer: g_pos", g_pos, gp, grad_tol(gp))
+    within("compiled vs python: g_pos", g_pos, got["python"][4], grad_tol(gp))
+
+
+def test_other_consumers_of_rast_are_added_to_the_prepared_share(dr, oracle):
+    b, res, G = _scene(seed=7)
+    Wm = np.random.default_rng(0).normal(size=(3,) + res + (4,)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    pos, attr, tri = _t(b["pos"], True), _t(b["attr"], True), _t(b["tri"])
+    c0 = _capi.host().counters()
+    rast, _ = dr.rasterize(ctx, pos, tri, res)
+    out, _ = dr.interpolate(attr, rast, tri)
+    ((out * _t(G)).sum() + (rast * _t(Wm)).sum()).backward()
+    _, _, _, ga, gr, gp = _chain(oracle, b, res, G, extra=Wm)
+    within("two contributors: g_attr", _np(attr.grad), ga, grad_tol(ga)); within("two contributors: g_pos", _np(pos.grad), gp, 2 * grad_tol(gp))
+    c1 = _capi.host().counters()
+    assert c1["fused"] == c0["fused"] + 1 and c1["fused_plus"] == c0["fused_plus"] + 1
+
+
+@pytest.mark.parametrize("how", ["hook", "retain_grad", "autograd_grad"])
+def test_whoever_looks_at_rasts_gradient_sees_the_reference_values(dr, oracle, how):
+    b, res, G = _scene(seed=11)
+    ctx = dr.RasterizeCudaContext()
+    pos, attr, tri = _t(b["pos"], True), _t(b["attr"], True), _t(b["tri"])
+    rast, _ = dr.rasterize(ctx, pos, tri, res)
+    out, _ = dr.interpolate(attr, rast, tri)
+    _, _, _, ga, gr, gp = _chain(oracle, b, res, G)
+    seen = []
+    c0 = _capi.host().counters()
+    if how == "hook":
+        rast.register_hook(lambda g: seen.append(g.clone()))
+        torch.autograd.backward(out, _t(G))
+    elif how == "retain_grad":
+        rast.retain_grad()
+        torch.autograd.backward(out, _t(G))
+        seen.append(rast.grad)
+    else:
+        g_rast, g_pos = torch.autograd.grad(out, [rast, pos], _t(G))
+        seen.append(g_rast)
+        within("autograd.grad: g_pos", _np(g_pos), gp, grad_tol(gp))
+    assert _capi.host().counters()["fused"] == c0["fused"]
+    within("g_rast as seen by " + how, _np(seen[0]), gr, grad_tol(gr))
+    if how != "autograd_grad":
+        within(how + ": g_pos", _np(pos.grad), gp, grad_tol(gp)); within(how + ": g_attr", _np(attr.grad), ga, grad_tol(ga))
+
+
+def test_pixel_differentials_range_mode_grad_db_false(dr, oracle):
+    b, res, G = _scene(n=2, seed=17)
+    rng = np.random.default_rng(1)
+    pos2, attr2 = b["pos"][0].copy(), b["attr"][0].copy()
+    T, A = b["tri"].shape[0], attr2.shape[-1]
+    ranges = np.array([[0, T // 2], [T // 2, T - T // 2]], np.int32)
+    Gda = rng.normal(size=(2,) + res + (2 * A,)).astype(np.float32)
+    ro, rdbo = oracle.rasterize(pos2, b["tri"], res, ranges=ranges)
+    ctx = dr.RasterizeCudaContext()
+    tri = _t(b["tri"])
+    for grad_db in (True, False):
+        pos, attr = _t(pos2, True), _t(attr2, True)
+        c0 = _capi.host().counters()
+        rast, rast_db = dr.rasterize(ctx, pos, tri, res, ranges=torch.from_numpy(ranges), grad_db=grad_db)
+        out, out_da = dr.interpolate(attr, rast, tri, rast_db=rast_db, diff_attrs="all")
+        torch.autograd.backward([out, out_da], [_t(G), _t(Gda)])
+        assert _capi.host().counters()["fused"] == c0["fused"] + 1
+        assert (_np(rast)[..., 3] != ro[..., 3]).sum() == 0
+        oo, odao = oracle.interpolate(attr2, ro, b["tri"], rast_db=rdbo, diff_attrs="all")
+        ga, gr, grdb = oracle.interpolate_grad(attr2, ro, b["tri"], G, rast_db=rdbo, dda=Gda, diff_attrs="all")
+        gp = oracle.rasterize_grad(pos2, b["tri"], ro, gr, grdb if grad_db else None)
+        within("range mode: out_da", _np(out_da), odao, grad_tol(odao))
+        within("range mode: g_attr", _np(attr.grad), ga, grad_tol(ga)); within("range mode: g_pos grad_db=%s" % grad_db, _np(pos.grad), gp, 2 * grad_tol(gp))
+
+
+def test_two_interpolations_and_antialias_on_one_rast(dr, oracle):
+    """Config 3's shape: rast is read by two interpolations and by antialias (which gives rast no gradient); both interpolations
+    prepare their share, pos also receives antialias' own gradient through autograd's sum."""
+    b, res, G = _scene(seed=19)
+    rng = np.random.default_rng(2)
+    attr_b = rng.normal(size=b["attr"].shape[:-1] + (3,)).astype(np.float32)
+    Gb = rng.normal(size=(3,) + res + (3,)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    pos, attr, attr2, tri = _t(b["pos"], True), _t(b["attr"], True), _t(attr_b, True), _t(b["tri"])
+    c0 = _capi.host().counters()
+    rast, _ = dr.rasterize(ctx, pos, tri, res)
+    o1, _ = dr.interpolate(attr, rast, tri)
+    o2, _ = dr.interpolate(attr2, rast, tri)
+    aa = dr.antialias(o2, rast, pos, tri)
+    torch.autograd.backward([o1, aa], [_t(G), _t(Gb)])
+    ro, _ = oracle.rasterize(b["pos"], b["tri"], res)
+    o2o, _ = oracle.interpolate(attr_b, ro, b["tri"])
+    g_col, g_pos_aa = oracle.antialias_grad(o2o, ro, b["pos"], b["tri"], Gb)
+    ga1, gr1, _ = oracle.interpolate_grad(b["attr"], ro, b["tri"], G)
+    ga2, gr2, _ = oracle.interpolate_grad(attr_b, ro, b["tri"], g_col)
+    gp = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr1 + gr2) + g_pos_aa
+    within("two interpolations: g_attr 1", _np(attr.grad), ga1, grad_tol(ga1)); within("two interpolations: g_attr 2", _np(attr2.grad), ga2, 2 * grad_tol(ga2))
+    within("two interpolations + antialias: g_pos", _np(pos.grad), gp, 3 * grad_tol(gp))
+    c1 = _capi.host().counters()
+    assert c1["fused"] == c0["fused"] + 2 and c1["fused_alone"] == c0["fused_alone"] + 1
+
+
+def test_records_and_texture_find_the_flags(dr, oracle):
+    b, res, G = _scene(seed=23)
+    rng = np.random.default_rng(3)
+    V = b["pos"].shape[1]
+    uvattr = rng.uniform(0, 1, size=(V, 2)).astype(np.float32)
+    tex_np = rng.uniform(size=(1, 64, 64, 3)).astype(np.float32)
+    ctx = dr.RasterizeCudaContext()
+    pos, uva, tex, tri = _t(b["pos"], True), _t(uvattr, True), _t(tex_np, True), _t(b["tri"])
+    rast, rast_db = dr.rasterize(ctx, pos, tri, res)
+    f = _plugin.flags_of(rast)
+    assert f is not None
+    n, (h, w) = rast.shape[0], res
+    want = torch.nn.functional.max_pool2d((rast[..., 3] > 0).float()[:, None], 8, ceil_mode=True)[:, 0] > 0
+    assert torch.equal(_plugin.tile_flags_grid(f, n, h, w) != 0, want)
+    assert _plugin.flags_of(rast.detach()) is not None and _plugin.flags_of(rast.clone()) is None and _plugin.flags_of(rast_db) is None
+    uv, uv_da = dr.interpolate(uva, rast, tri, rast_db=rast_db, diff_attrs="all")
+    assert _plugin.flags_of(uv, "zero").data_ptr() == f.data_ptr() and _plugin.flags_of(uv_da, "zero").data_ptr() == f.data_ptr()
+    col = dr.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear")
+    aa = dr.antialias(col, rast, pos, tri)
+    dy = rng.normal(size=aa.shape).astype(np.float32)
+    aa.backward(_t(dy))
+    # the same with every flag ignored: identical forward values (skipping never changes what is computed)
+    _plugin.set_tile_skipping(False)
+    try:
+        assert _plugin.flags_of(rast) is None
+        pos2, uva2, tex2 = _t(b["pos"], True), _t(uvattr, True), _t(tex_np, True)
+        r2, rdb2 = dr.rasterize(ctx, pos2, tri, res)
+        uv2, uvda2 = dr.interpolate(uva2, r2, tri, rast_db=rdb2, diff_attrs="all")
+        col2 = dr.texture(tex2, uv2, uvda2, filter_mode="linear-mipmap-linear")
+        aa2 = dr.antialias(col2, r2, pos2, tri)
+        aa2.backward(_t(dy))
+    finally:
+        _plugin.set_tile_skipping(True)
+    assert torch.equal(uv, uv2) and torch.equal(uv_da, uvda2)             # zeros are written either way
+    within("flags vs none: antialiased colour", _np(aa), _np(aa2), ATOL)  # (a tile of known-zero uv is sampled once, by scalar arithmetic)
+    within("flags vs none: g_tex", _np(tex.grad), _np(tex2.grad), grad_tol(_np(tex2.grad)))
+    within("flags vs none: g_pos", _np(pos.grad), _np(pos2.grad), grad_tol(_np(pos2.grad)))
+    within("flags vs none: g_uvattr", _np(uva.grad), _np(uva2.grad), grad_tol(_np(uva2.grad)))
+    with torch.no_grad():
+        rast.mul_(1.0)
+    assert _plugin.flags_of(rast) is None                                 # version counter moved
+
+
+def test_depth_peeling_and_errors_still_worded_by_the_python_layer(dr, oracle):
+    b, res, G = _scene(seed=41)
+    ctx = dr.RasterizeCudaContext()
+    pos, tri = _t(b["pos"]), _t(b["tri"])
+    depth = None
+    with dr.DepthPeeler(ctx, pos, tri, res) as peeler:
+        for k in range(3):
+            rast, _ = peeler.rasterize_next_layer()
+            want, _, depth = oracle.rasterize(b["pos"], b["tri"], res, peel_depth=depth, return_depth=True)
+            assert (_np(rast)[..., 3] != want[..., 3]).sum() == 0, "layer %d" % k
+    with pytest.raises(RuntimeError, match="must reside on the same GPU device"):
+        dr.rasterize(ctx, pos.cpu(), tri, res)
+    with pytest.raises(RuntimeError, match="must be float32 tensors"):
+        dr.rasterize(ctx, pos.double(), tri, res)
+    rast, _ = dr.rasterize(ctx, pos, tri, res)
+    with pytest.raises(RuntimeError, match="must be contiguous tensors"):
+        dr.interpolate(_t(b["attr"])[..., :2], rast, tri)
+
+
+def test_the_step_captures_into_a_graph_and_replays(dr, oracle):
+    b, res, G = _scene(seed=43)
+    ctx = dr.RasterizeCudaContext()
+    pos, attr, tri, Gt = _t(b["pos"], True), _t(b["attr"], True), _t(b["tri"]), _t(G)
+
+    def step():
+        rast, _ = dr.rasterize(ctx, pos, tri, res)
+        out, _ = dr.interpolate(attr, rast, tri)
+        torch.autograd.backward(out, Gt)
+        return out
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            pos.grad = attr.grad = None
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    pos.grad = attr.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    with torch.no_grad():
+        pos.mul_(0.97)                                                   # new inputs in the captured tensors
+        pos.grad.zero_(); attr.grad.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    b2 = dict(b, pos=_np(pos))
+    _, _, oo, ga, _, gp = _chain(oracle, b2, res, G)
+    within("graph replay: out", _np(out), oo, ATOL)
+    within("graph replay: g_attr", _np(attr.grad), ga, grad_tol(ga)); within("graph replay: g_pos", _np(pos.grad), gp, grad_tol(gp))
+    assert ctx.cpp_wrapper.host_state(_capi.host()).captured

@@ -9,7 +9,9 @@ from conftest import ATOL, grad_tol, within
 from nvdiffrast_amd.torch import _plugin
 from nvdiffrast_amd.utils import m10k_batch, stress_triangles
 
-pytestmark = pytest.mark.gpu
+# These tests look INSIDE the Python host layer (the records on the tensors, the stand-in gradient, the discard rule): they run
+# with that layer serving every call.  tests/test_gpu_host_layer.py asks the same questions of the compiled layer.
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("python_host_layer")]
 
 
 def _t(a, dev="cuda"):

@@ -35,6 +35,18 @@ def test_rasterizer_tests_with_a_triangle_list_for_every_bin():
     assert " passed" in r.stdout
 
 
+def test_gpu_suite_on_the_python_host_layer():
+    """NVDR_HOST=0: rasterize() and interpolate() served by torch/_plugin.py + the Python autograd node instead of the compiled
+    host layer (csrc_host/nvdr_torch_host.cpp) -- what a box without the built module runs."""
+    env = dict(os.environ, NVDR_HOST="0")
+    files = ["test_gpu_raster_interp.py", "test_gpu_end_to_end.py", "test_gpu_edge_cases.py", "test_gpu_fuzz.py", "test_gpu_work_order.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest"] + [os.path.join(ROOT, "tests", f) for f in files] +
+                       ["-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1800, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_gpu_suite_with_tile_flag_verification():
     """NVDR_VERIFY_TILE_FLAGS=1: every use of tile flags anywhere in these files re-derives them from the tensor actually passed
     and fails on a mismatch (legality rests on pointer / version / shape; this run checks the claim itself)."""

@@ -86,7 +86,7 @@ def test_separate_backward_kernels_on_an_ordered_launch(dr, raw_oracle):
     dy = rng.normal(size=(n,) + res + (4,)).astype(np.float32)
     ctx = dr.RasterizeCudaContext()
     rast, _ = dr.rasterize(ctx, _t(b["pos"]), _t(b["tri"]), res)
-    flags = rast._nvdr_origin.flags_for(rast)
+    flags = _plugin.flags_of(rast)
     g_attr, g_rast = _plugin.interpolate_grad(_t(attr), rast, _t(b["tri"]), _t(dy), tile_flags=flags)
     g_pos = _plugin.rasterize_grad(_t(b["pos"]), _t(b["tri"]), rast, g_rast, tile_flags=flags)
     rh = _np(rast)
@@ -125,7 +125,7 @@ def test_orders_without_a_second_part(dr, raw_oracle, case):
     tex = _t(tex_np).requires_grad_(True)
     tri = _t(tri_np)
     rast, rast_db = dr.rasterize(ctx, pos, tri, res)
-    grid = _plugin.tile_flags_grid(rast._nvdr_origin.flags, n, *res)
+    grid = _plugin.tile_flags_grid(_plugin.flags_of(rast), n, *res)
     assert int(grid.sum()) == (0 if case == "nothing visible" else grid.numel())
     uv, uv_da = dr.interpolate(attr, rast, tri, rast_db=rast_db, diff_attrs="all")
     uv.retain_grad(); uv_da.retain_grad()
