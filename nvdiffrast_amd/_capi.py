@@ -143,7 +143,8 @@ _host = None
 _host_tried = False
 _HOST_SYMBOLS = ("nvdr_last_error", "nvdr_get_option", "nvdr_log", "nvdr_rasterize_scratch_bytes_pool", "nvdr_rasterize_pool_peak_offset",
                  "nvdr_tile_flags_bytes", "nvdr_rasterize_fwd", "nvdr_rasterize_grad", "nvdr_interpolate_fwd", "nvdr_interpolate_grad",
-                 "nvdr_interpolate_rasterize_grad")
+                 "nvdr_interpolate_rasterize_grad", "nvdr_texture_mip_info", "nvdr_texture_construct_mip", "nvdr_texture_fwd",
+                 "nvdr_texture_grad", "nvdr_texture_grad_scratch_bytes", "nvdr_antialias_fwd", "nvdr_antialias_grad")
 
 
 def host():

@@ -1,8 +1,9 @@
-// nvdr_torch_host.cpp -- the compiled host layer of rasterize() and interpolate().
+// nvdr_torch_host.cpp -- the compiled host layer of rasterize(), interpolate(), texture() and antialias().
 //
 // What csrc/torch/torch_rasterize.cpp:43-263 and csrc/torch/torch_interpolate.cpp:42-248 are in the reference -- validate the
-// tensors, allocate outputs with torch, launch on torch's current stream -- for the two ops of the metric's graph, PLUS their
-// autograd nodes (Python in the reference: nvdiffrast/torch/ops.py:75-90, 210-258).  With small batches the step time of this
+// tensors, allocate outputs with torch, launch on torch's current stream -- for the two ops of the metric's graph and, further
+// down, what torch_texture.cpp:98-716 and torch_antialias.cpp:68-241 are for the other two, PLUS the autograd nodes of all four
+// (Python in the reference: nvdiffrast/torch/ops.py:75-90, 210-258, 261-375, 466-490).  With small batches the step time of this
 // path is the host's; here a step of rasterize -> interpolate -> backward crosses into Python four times (two calls, their two
 // returns) instead of running ~90 us of interpreter per step.
 //
@@ -59,6 +60,13 @@ struct Api {
     decltype(&nvdr_interpolate_fwd) interpolate_fwd = nullptr;
     decltype(&nvdr_interpolate_grad) interpolate_grad = nullptr;
     decltype(&nvdr_interpolate_rasterize_grad) interpolate_rasterize_grad = nullptr;
+    decltype(&nvdr_texture_mip_info) texture_mip_info = nullptr;
+    decltype(&nvdr_texture_construct_mip) texture_construct_mip = nullptr;
+    decltype(&nvdr_texture_fwd) texture_fwd = nullptr;
+    decltype(&nvdr_texture_grad) texture_grad = nullptr;
+    decltype(&nvdr_texture_grad_scratch_bytes) texture_grad_scratch_bytes = nullptr;
+    decltype(&nvdr_antialias_fwd) antialias_fwd = nullptr;
+    decltype(&nvdr_antialias_grad) antialias_grad = nullptr;
     bool ready = false;
 } api;
 
@@ -79,6 +87,13 @@ void init(const py::dict& addrs) {
     take(api.interpolate_fwd, addrs, "nvdr_interpolate_fwd");
     take(api.interpolate_grad, addrs, "nvdr_interpolate_grad");
     take(api.interpolate_rasterize_grad, addrs, "nvdr_interpolate_rasterize_grad");
+    take(api.texture_mip_info, addrs, "nvdr_texture_mip_info");
+    take(api.texture_construct_mip, addrs, "nvdr_texture_construct_mip");
+    take(api.texture_fwd, addrs, "nvdr_texture_fwd");
+    take(api.texture_grad, addrs, "nvdr_texture_grad");
+    take(api.texture_grad_scratch_bytes, addrs, "nvdr_texture_grad_scratch_bytes");
+    take(api.antialias_fwd, addrs, "nvdr_antialias_fwd");
+    take(api.antialias_grad, addrs, "nvdr_antialias_grad");
     api.ready = true;
 }
 
@@ -543,6 +558,282 @@ RastPair interpolate(const at::Tensor& attr, const at::Tensor& rast, const at::T
     return std::make_tuple(std::move(out), std::move(out_da));
 }
 
+// --------------------------------------------------------------------------------------------------------------- texture
+// torch_texture.cpp:98-716 for 2-D and cube textures with the internal mip chain (a TextureMipWrapper's flat buffer); custom mip
+// stacks -- per-level tensors with gradients of their own -- stay with the Python layer.
+constexpr int kTexMaxLevels = 17;
+enum { FILTER_NEAREST = 0, FILTER_LINEAR = 1, FILTER_LMN = 2, FILTER_LML = 3, BOUNDARY_CUBE = 0 };
+
+struct TexGeom {
+    bool cube;
+    int64_t tn, th, tw, C;
+};
+
+bool tex_geom(const at::Tensor& tex, bool cube, TexGeom& g) {
+    if (!cube) {
+        if (!(tex.dim() == 4 && tex.size(0) > 0 && tex.size(1) > 0 && tex.size(2) > 0 && tex.size(3) > 0)) return false;
+        g = {false, tex.size(0), tex.size(1), tex.size(2), tex.size(3)};
+    } else {
+        if (!(tex.dim() == 5 && tex.size(0) > 0 && tex.size(1) == 6 && tex.size(2) > 0 && tex.size(3) > 0 && tex.size(4) > 0 && tex.size(2) == tex.size(3))) return false;
+        g = {true, tex.size(0), tex.size(2), tex.size(3), tex.size(4)};
+    }
+    return g.tw <= (1 << 16) && g.th <= (1 << 16) && g.tn <= INT32_MAX && g.C <= INT32_MAX;
+}
+
+struct MipLevels {
+    int L = 0;
+    int64_t off[kTexMaxLevels] = {0};
+    int64_t total = 0;
+};
+
+bool mip_levels(const TexGeom& g, int64_t max_mip_level, MipLevels& m) {
+    int lw[kTexMaxLevels], lh[kTexMaxLevels];
+    m.L = api.texture_mip_info((int)g.tn, (int)g.th, (int)g.tw, (int)g.C, (int)g.cube, (int)max_mip_level, lw, lh, m.off, &m.total);
+    return m.L >= 0;
+}
+
+// texture_construct_mip (torch_texture.cpp:98-169): the flat buffer of levels 1..L, or None (bad extents, unusual tensor: the
+// Python layer words the error).
+std::optional<at::Tensor> construct_mip(const at::Tensor& tex, int64_t max_mip_level, bool cube) {
+    if (!api.ready || max_mip_level < -1) return std::nullopt;
+    TexGeom g;
+    if (!(on_gpu(tex) && tex.scalar_type() == at::kFloat && tex.is_contiguous() && tex_geom(tex, cube, g))) return std::nullopt;
+    MipLevels m;
+    if (!mip_levels(g, max_mip_level, m)) return std::nullopt;
+    OnDevice guard(tex.device());
+    at::Tensor mip = at::empty({m.total}, tex.options());
+    check(api.texture_construct_mip(tex.data_ptr<float>(), (int)g.tn, (int)g.th, (int)g.tw, (int)g.C, (int)cube, (int)max_mip_level,
+                                    mip.data_ptr<float>(), stream_of(index_of(tex))),
+          "texture_construct_mip");
+    return mip;
+}
+
+at::Tensor zero_flags_of(const at::Tensor& uv, const at::Tensor& uv_da) {
+    at::Tensor f = flags_of(uv, KIND_ZERO);
+    if (f.defined() && uv_da.defined() && uv_da.numel() > 0) {
+        at::Tensor fd = flags_of(uv_da, KIND_ZERO);
+        if (!fd.defined() || fd.data_ptr() != f.data_ptr()) return {};
+    }
+    return f;
+}
+
+struct TextureNode : public Node {
+    SavedVariable tex_, uv_, uv_da_, bias_;
+    at::Tensor mip_, flags_;
+    int filter_ = 0, boundary_ = 0;
+    int64_t max_mip_level_ = 0;
+    bool scratch_ = true;
+
+    std::string name() const override { return "NvdrTextureBackward"; }
+    void release_variables() override { tex_.reset_data(); uv_.reset_data(); uv_da_.reset_data(); bias_.reset_data(); mip_.reset(); flags_.reset(); }
+
+    variable_list apply(variable_list&& grads) override {
+        variable_list result(4);
+        at::Tensor dy = grads.size() > 0 ? grads[0] : at::Tensor();
+        if (!dy.defined()) return result;
+        at::Tensor tex = tex_.unpack(), uv = uv_.unpack();
+        const bool mipmapped = filter_ == FILTER_LMN || filter_ == FILTER_LML;
+        at::Tensor uv_da = mipmapped ? uv_da_.unpack() : at::Tensor(), bias = mipmapped ? bias_.unpack() : at::Tensor();
+        const bool has_da = uv_da.defined() && uv_da.numel() > 0, has_bias = bias.defined() && bias.numel() > 0;
+        const bool cube = boundary_ == BOUNDARY_CUBE;
+        TexGeom g;
+        TORCH_CHECK(tex_geom(tex, cube, g), "texture_grad(): tex must have shape[>0, >0, >0, >0]");
+        const int64_t n = uv.size(0), H = uv.size(1), W = uv.size(2);
+        const c10::Device dev = tex.device();
+        TORCH_CHECK(on_gpu(dy) && dy.device() == dev, "texture_grad_linear_mipmap_linear(): Inputs dy must reside on the same GPU device");
+        TORCH_CHECK(dy.scalar_type() == at::kFloat, "texture_grad_linear_mipmap_linear(): Inputs dy must be float32 tensors");
+        TORCH_CHECK(dy.dim() == 4 && dy.size(0) == n && dy.size(1) == H && dy.size(2) == W && dy.size(3) == g.C,
+                    "texture_grad_linear_mipmap_linear(): dy must have shape [minibatch_size, height, width, channels]");
+        dy = dy.contiguous();
+        OnDevice guard(dev);
+        MipLevels m;
+        const float* ptrs[kTexMaxLevels] = {nullptr};
+        float* gptrs[kTexMaxLevels] = {nullptr};
+        at::Tensor g_flat;
+        if (mipmapped) {
+            TORCH_CHECK(mip_levels(g, max_mip_level_, m) && mip_.defined() && mip_.numel() == m.total, "texture_grad(): wrapped mip tensor size mismatch");
+            g_flat = at::zeros_like(mip_);
+            for (int i = 1; i <= m.L; i++) { ptrs[i - 1] = mip_.data_ptr<float>() + m.off[i]; gptrs[i - 1] = g_flat.data_ptr<float>() + m.off[i]; }
+        }
+        at::Tensor g_tex = at::zeros_like(tex), g_uv, g_uv_da, g_bias;
+        if (filter_ != FILTER_NEAREST) {
+            g_uv = at::empty_like(uv);
+            if (filter_ == FILTER_LML) {
+                if (has_da) g_uv_da = at::empty_like(uv_da);
+                if (has_bias) g_bias = at::empty_like(bias);
+            }
+        }
+        // the flags the forward pass used, if uv / uv_da still are what interpolate wrote (asked again: the records go by version)
+        const uint8_t* flags = nullptr;
+        if (flags_.defined() && !cube) {
+            at::Tensor now = zero_flags_of(uv, (mipmapped && has_da) ? uv_da : at::Tensor());
+            if (now.defined() && now.data_ptr() == flags_.data_ptr()) flags = flags_.data_ptr<uint8_t>();
+        }
+        at::Tensor scratch;                                    // two-level reduction of constant-uv regions (include/nvdr_hip.h)
+        if (scratch_ && filter_ != FILTER_NEAREST && !cube && n * H * W >= 4096)
+            scratch = at::empty({(int64_t)(api.texture_grad_scratch_bytes((int)n, (int)H, (int)W, (int)g.C) / 4)}, at::TensorOptions().dtype(at::kInt).device(dev));
+        check(api.texture_grad(tex.data_ptr<float>(), mipmapped ? ptrs : nullptr, m.L, uv.data_ptr<float>(),
+                               (mipmapped && has_da) ? uv_da.data_ptr<float>() : nullptr, (mipmapped && has_bias) ? bias.data_ptr<float>() : nullptr,
+                               dy.data_ptr<float>(), (int)g.tn, (int)g.th, (int)g.tw, (int)g.C, (int)n, (int)H, (int)W,
+                               filter_, boundary_, (int)mipmapped, g_tex.data_ptr<float>(), mipmapped ? gptrs : nullptr,
+                               g_uv.defined() ? g_uv.data_ptr<float>() : nullptr, g_uv_da.defined() ? g_uv_da.data_ptr<float>() : nullptr,
+                               g_bias.defined() ? g_bias.data_ptr<float>() : nullptr,
+                               scratch.defined() ? scratch.data_ptr() : nullptr, scratch.defined() ? (size_t)scratch.numel() * 4 : 0,
+                               flags, stream_of(index_of(tex))),
+              "texture_grad");
+        result[0] = std::move(g_tex);
+        result[1] = std::move(g_uv);
+        result[2] = std::move(g_uv_da);
+        result[3] = std::move(g_bias);
+        return result;
+    }
+};
+
+// texture_fwd / texture_fwd_mip (torch_texture.cpp:174-416).  mip: the wrapper's flat buffer (mipmapped filters), with the
+// wrapper's max_mip_level, texture_size and cube_mode for the consistency check of torch_texture.cpp:309-310.
+std::optional<at::Tensor> texture_op(const at::Tensor& tex, const at::Tensor& uv, const std::optional<at::Tensor>& uv_da_opt,
+                                  const std::optional<at::Tensor>& bias_opt, const std::optional<at::Tensor>& mip_opt, int64_t max_mip_level,
+                                  const std::vector<int64_t>& mip_texture_size, bool mip_cube, int64_t filter, int64_t boundary, bool grad_scratch) {
+    if (!api.ready || g_verify.load(std::memory_order_relaxed) || filter < 0 || filter > 3 || boundary < 0 || boundary > 3) return std::nullopt;
+    const bool cube = boundary == BOUNDARY_CUBE, mipmapped = filter == FILTER_LMN || filter == FILTER_LML;
+    TexGeom g;
+    if (!(on_gpu(tex) && uv.device() == tex.device() && tex.scalar_type() == at::kFloat && uv.scalar_type() == at::kFloat &&
+          tex.is_contiguous() && uv.is_contiguous() && tex_geom(tex, cube, g) &&
+          uv.dim() == 4 && uv.size(0) > 0 && uv.size(1) > 0 && uv.size(2) > 0 && uv.size(3) == (cube ? 3 : 2) &&
+          (g.tn == 1 || g.tn == uv.size(0))))
+        return std::nullopt;
+    const c10::Device dev = tex.device();
+    const int64_t n = uv.size(0), H = uv.size(1), W = uv.size(2);
+    if (n > INT32_MAX || H > INT32_MAX || W > INT32_MAX) return std::nullopt;
+    at::Tensor uv_da, bias, mip;
+    bool has_da = false, has_bias = false;
+    MipLevels m;
+    const float* ptrs[kTexMaxLevels] = {nullptr};
+    if (mipmapped) {
+        if (uv_da_opt.has_value() && uv_da_opt->defined()) uv_da = *uv_da_opt;
+        if (bias_opt.has_value() && bias_opt->defined()) bias = *bias_opt;
+        has_da = uv_da.defined() && uv_da.numel() > 0;
+        has_bias = bias.defined() && bias.numel() > 0;
+        if (!(has_da || has_bias) || !mip_opt.has_value() || !mip_opt->defined() || max_mip_level < -1) return std::nullopt;
+        mip = *mip_opt;
+        auto ok = [&](const at::Tensor& t) { return t.device() == dev && t.scalar_type() == at::kFloat && t.is_contiguous(); };
+        if (!ok(mip) || (has_da && !(ok(uv_da) && uv_da.dim() == 4 && uv_da.size(0) == n && uv_da.size(1) == H && uv_da.size(2) == W && uv_da.size(3) == (cube ? 6 : 4))) ||
+            (has_bias && !(ok(bias) && bias.dim() == 3 && bias.size(0) == n && bias.size(1) == H && bias.size(2) == W)))
+            return std::nullopt;
+        if (mip_cube != cube || !tex.sizes().equals(mip_texture_size) || !mip_levels(g, max_mip_level, m) || mip.dim() != 1 || mip.size(0) != m.total)
+            return std::nullopt;
+        for (int i = 1; i <= m.L; i++) ptrs[i - 1] = mip.data_ptr<float>() + m.off[i];
+    }
+    at::Tensor flags = cube ? at::Tensor() : zero_flags_of(uv, (mipmapped && has_da) ? uv_da : at::Tensor());
+    OnDevice guard(dev);
+    at::Tensor out = at::empty({n, H, W, g.C}, tex.options());
+    check(api.texture_fwd(tex.data_ptr<float>(), mipmapped ? ptrs : nullptr, m.L, uv.data_ptr<float>(),
+                          (mipmapped && has_da) ? uv_da.data_ptr<float>() : nullptr, (mipmapped && has_bias) ? bias.data_ptr<float>() : nullptr,
+                          (int)g.tn, (int)g.th, (int)g.tw, (int)g.C, (int)n, (int)H, (int)W, (int)filter, (int)boundary,
+                          out.data_ptr<float>(), flags.defined() ? flags.data_ptr<uint8_t>() : nullptr, stream_of(index_of(tex))),
+          mipmapped ? "texture_fwd_mip" : "texture_fwd");
+    g_n_fast_fwd++;
+    if (torch::autograd::compute_requires_grad(tex, uv, uv_da, bias)) {
+        auto node = std::shared_ptr<TextureNode>(new TextureNode(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(tex, uv, uv_da, bias));
+        node->tex_ = SavedVariable(tex, false);
+        node->uv_ = SavedVariable(uv, false);
+        if (mipmapped) {
+            // (absent optional tensors are saved as empty ones, as the reference's ops.py does: ops.py:301-307)
+            node->uv_da_ = SavedVariable(uv_da.defined() ? uv_da : at::empty({0}, tex.options()), false);
+            node->bias_ = SavedVariable(bias.defined() ? bias : at::empty({0}, tex.options()), false);
+            node->mip_ = mip;
+        }
+        node->flags_ = flags;
+        node->filter_ = (int)filter;
+        node->boundary_ = (int)boundary;
+        node->max_mip_level_ = max_mip_level;
+        node->scratch_ = grad_scratch;
+        torch::autograd::set_history(out, node);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------- antialias
+struct AntialiasNode : public Node {
+    SavedVariable color_, rast_, pos_, tri_;
+    at::Tensor work_;
+    double boost_ = 1.0;
+
+    std::string name() const override { return "NvdrAntialiasBackward"; }
+    void release_variables() override { color_.reset_data(); rast_.reset_data(); pos_.reset_data(); tri_.reset_data(); work_.reset(); }
+
+    variable_list apply(variable_list&& grads) override {
+        variable_list result(2);
+        at::Tensor dy = grads.size() > 0 ? grads[0] : at::Tensor();
+        if (!dy.defined()) return result;
+        at::Tensor color = color_.unpack(), rast = rast_.unpack(), pos = pos_.unpack(), tri = tri_.unpack();
+        const c10::Device dev = color.device();
+        TORCH_CHECK(on_gpu(dy) && dy.device() == dev, "antialias_grad(): Inputs color, rast, pos, tri, dy, work_buffer must reside on the same GPU device");
+        TORCH_CHECK(dy.scalar_type() == at::kFloat, "antialias_grad(): Inputs color, rast, pos, dy, work_buffer must be float32 tensors");
+        TORCH_CHECK(dy.dim() == 4 && dy.sizes().equals(color.sizes()), "antialias_grad(): color and dy inputs must have same dimensions");
+        dy = dy.contiguous();
+        const bool instance = pos.dim() > 2;
+        OnDevice guard(dev);
+        at::Tensor g_color = at::empty_like(dy);                // the library copies dy into it
+        at::Tensor g_pos = at::zeros_like(pos);
+        check(api.antialias_grad(color.data_ptr<float>(), rast.data_ptr<float>(), pos.data_ptr<float>(), tri.data_ptr<int32_t>(),
+                                 dy.data_ptr<float>(), work_.data_ptr<float>(), (size_t)work_.numel() * 4, (int)instance,
+                                 (int)color.size(0), (int)(instance ? pos.size(1) : pos.size(0)), (int)tri.size(0),
+                                 (int)color.size(1), (int)color.size(2), (int)color.size(3),
+                                 g_color.data_ptr<float>(), g_pos.data_ptr<float>(), stream_of(index_of(color))),
+              "antialias_grad");
+        if (boost_ != 1.0) g_pos.mul_(boost_);
+        result[0] = std::move(g_color);
+        result[1] = std::move(g_pos);
+        return result;
+    }
+};
+
+// antialias_fwd (torch_antialias.cpp:68-155).  ev_hash: the TopologyHashWrapper's table.
+std::optional<at::Tensor> antialias_op(const at::Tensor& color, const at::Tensor& rast, const at::Tensor& pos, const at::Tensor& tri,
+                                    const at::Tensor& ev_hash, double boost) {
+    if (!api.ready || g_verify.load(std::memory_order_relaxed)) return std::nullopt;
+    const c10::Device dev = color.device();
+    const bool instance = pos.dim() > 2;
+    if (!(on_gpu(color) && rast.device() == dev && pos.device() == dev && tri.device() == dev && ev_hash.device() == dev &&
+          color.scalar_type() == at::kFloat && rast.scalar_type() == at::kFloat && pos.scalar_type() == at::kFloat &&
+          tri.scalar_type() == at::kInt && ev_hash.scalar_type() == at::kInt &&
+          color.is_contiguous() && rast.is_contiguous() && pos.is_contiguous() && tri.is_contiguous() && ev_hash.is_contiguous() &&
+          color.dim() == 4 && color.size(0) > 0 && color.size(1) > 0 && color.size(2) > 0 && color.size(3) > 0 &&
+          rast.dim() == 4 && rast.size(0) == color.size(0) && rast.size(1) == color.size(1) && rast.size(2) == color.size(2) && rast.size(3) == 4 &&
+          tri.dim() == 2 && tri.size(0) > 0 && tri.size(1) == 3 && ev_hash.dim() == 1))
+        return std::nullopt;
+    if (instance ? !(pos.dim() == 3 && pos.size(0) == color.size(0) && pos.size(1) > 0 && pos.size(2) == 4)
+                 : !(pos.dim() == 2 && pos.size(0) > 0 && pos.size(1) == 4))
+        return std::nullopt;
+    const int64_t N = color.size(0), H = color.size(1), W = color.size(2), C = color.size(3);
+    if (N > INT32_MAX || H > INT32_MAX || W > INT32_MAX || C > INT32_MAX || N * H * W * 8 + 4 > (int64_t)INT32_MAX * 16) return std::nullopt;
+    at::Tensor flags = flags_of(rast, KIND_RAST);
+    OnDevice guard(dev);
+    at::Tensor out = at::empty_like(color);                     // the library copies color into it
+    at::Tensor work = at::empty({N * W * H * 8 + 4}, color.options());
+    check(api.antialias_fwd(color.data_ptr<float>(), rast.data_ptr<float>(), pos.data_ptr<float>(), tri.data_ptr<int32_t>(),
+                            ev_hash.data_ptr<int32_t>(), (size_t)ev_hash.numel() * 4, (int)instance, (int)N,
+                            (int)(instance ? pos.size(1) : pos.size(0)), (int)tri.size(0), (int)H, (int)W, (int)C,
+                            out.data_ptr<float>(), work.data_ptr<float>(), (size_t)work.numel() * 4,
+                            flags.defined() ? flags.data_ptr<uint8_t>() : nullptr, stream_of(index_of(color))),
+          "antialias_fwd");
+    g_n_fast_fwd++;
+    if (torch::autograd::compute_requires_grad(color, pos)) {
+        auto node = std::shared_ptr<AntialiasNode>(new AntialiasNode(), torch::autograd::deleteNode);
+        node->set_next_edges(torch::autograd::collect_next_edges(color, pos));
+        node->color_ = SavedVariable(color, false);
+        node->rast_ = SavedVariable(rast, false);
+        node->pos_ = SavedVariable(pos, false);
+        node->tri_ = SavedVariable(tri, false);
+        node->work_ = work;
+        node->boost_ = boost;
+        torch::autograd::set_history(out, node);
+    }
+    return out;
+}
+
 py::dict counters() {
     py::dict d;
     d["fused"] = (long long)g_n_fused;                  // interpolate backward passes that prepared a share of the position gradient
@@ -562,11 +853,21 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         .def_readonly("device_idx", &RasterState::device_idx)
         .def_readonly("captured", &RasterState::captured)
         .def_property_readonly("scratch_bytes", &RasterState::scratch_numel)
-        .def_property_readonly("retired", [](const RasterState& s) { return (int)s.retired.size(); });
+        .def_property_readonly("retired", [](const RasterState& s) { return (int)s.retired.size(); })
+        // the depth surfaces of the last DepthPeeler pass and the clip-pool bookkeeping, for tests and tools
+        .def_property_readonly("depth", [](const RasterState& s) -> std::optional<at::Tensor> { if (!s.depth.defined()) return std::nullopt; return s.depth; })
+        .def_property_readonly("peel", [](const RasterState& s) -> std::optional<at::Tensor> { if (!s.peel.defined()) return std::nullopt; return s.peel; })
+        .def("poison_scratch", [](RasterState& s, int value) { if (s.scratch.defined()) s.scratch.fill_(value); s.has_clean = false; })
+        .def("set_scratch", [](RasterState& s, const at::Tensor& t) { s.scratch = t; s.has_clean = false; })
+        .def("set_pool", [](RasterState& s, int64_t n, int64_t max_tri, int64_t slots) { s.pools[{n, max_tri}] = slots; })
+        .def("get_pool", [](const RasterState& s, int64_t n, int64_t max_tri) -> int64_t { auto it = s.pools.find({n, max_tri}); return it == s.pools.end() ? -1 : it->second; });
     m.def("init", &init);
     m.def("ready", []() { return api.ready; });
     m.def("rasterize", &rasterize, py::call_guard<py::gil_scoped_release>());
     m.def("interpolate", &interpolate, py::call_guard<py::gil_scoped_release>());
+    m.def("construct_mip", &construct_mip, py::call_guard<py::gil_scoped_release>());
+    m.def("texture", &texture_op, py::call_guard<py::gil_scoped_release>());
+    m.def("antialias", &antialias_op, py::call_guard<py::gil_scoped_release>());
     m.def("attach", &attach);
     m.def("flags_of", [](const at::Tensor& t, int kind) -> std::optional<at::Tensor> {
         at::Tensor f = flags_of(t, kind);

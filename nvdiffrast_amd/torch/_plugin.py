@@ -237,6 +237,28 @@ class RasterizeCRStateWrapper:
             self._host = host.RasterState(self.cuda_device_idx)
         return self._host
 
+    # -- what tests and tools look at, whichever host layer serves the context
+    def poison_scratch(self, value=0):
+        """Overwrite the rasterizer's scratch (both layers' buffers) and forget that it was left clean."""
+        if self.scratch is not None:
+            self.scratch.fill_(value)
+        self.clean_layout = None
+        if self._host is not None:
+            self._host.poison_scratch(value)
+
+    def set_pool_hint(self, n, max_tri, slots):
+        self.pools[(n, max_tri)] = slots
+        h = host_layer()
+        if h is not None:
+            self.host_state(h).set_pool(n, max_tri, slots)
+
+    def pool_slots(self, n, max_tri):
+        """Clip-pool slots per image remembered for this shape by the layer that serves the context (-1: none yet)."""
+        h = host_layer()
+        if h is not None:
+            return self.host_state(h).get_pool(n, max_tri)
+        return self.pools.get((n, max_tri), -1)
+
     def get_scratch(self, nbytes, device, layout):
         """Returns (buffer, clean): `clean` tells the library that the buffer's control block is as this
         context's previous successful call with the same layout left it (include/nvdr_hip.h).
@@ -1050,6 +1072,13 @@ def _tex_dims(tex, cube_mode):
 def texture_construct_mip(tex, max_mip_level, cube_mode):
     """torch_texture.cpp:98-169."""
     fn = "texture_construct_mip"
+    h = host_layer()
+    if h is not None:
+        mip = h.construct_mip(tex, int(max_mip_level), bool(cube_mode))      # None: not the ordinary case -> the checks below word it
+        if mip is not None:
+            w = TextureMipWrapper()
+            w.mip, w.max_mip_level, w.texture_size, w.cube_mode = mip, int(max_mip_level), list(tex.shape), bool(cube_mode)
+            return w
     _require(max_mip_level >= -1, fn, "invalid max_mip_level")
     dev = _check_device(fn, tex=tex)
     _check_contiguous(fn, tex=tex)

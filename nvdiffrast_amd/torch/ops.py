@@ -471,9 +471,11 @@ def _rasterize_layer(glctx, pos, tri, resolution, ranges, grad_db, peeling_idx):
     autograd node in C++) when it is there and takes the call, else the Python one (_plugin: rare modes, every error message)."""
     host = _plugin.host_layer()
     if host is not None and len(resolution) == 2:
-        served = host.rasterize(glctx.cpp_wrapper.host_state(host), pos, tri, int(resolution[0]), int(resolution[1]), ranges,
-                                grad_db, peeling_idx)
+        state = glctx.cpp_wrapper.host_state(host)
+        served = host.rasterize(state, pos, tri, int(resolution[0]), int(resolution[1]), ranges, grad_db, peeling_idx)
         if served is not None:
+            if peeling_idx >= 0:
+                glctx.cpp_wrapper.depth, glctx.cpp_wrapper.peel = state.depth, state.peel      # (where tools and tests look for them)
             return served
     return _Dispatch.apply(_RasterizeOp, glctx, pos, tri, resolution, ranges, grad_db, peeling_idx)
 
@@ -602,7 +604,12 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="aut
     filter_mode = _resolve_filter_mode(filter_mode, uv_da, mip_level_bias, limit)
     _FILTER_MODES[filter_mode]                              # KeyError for an unknown mode, as the reference's dict lookup
     boundary = _BOUNDARY_MODES[boundary_mode]
+    host = _plugin.host_layer()                             # (see _rasterize_layer)
     if filter_mode not in _MIPMAPPED:
+        if host is not None:
+            served = host.texture(tex, uv, None, None, None, 0, [], False, _FILTER_MODES[filter_mode], boundary, _plugin._TEX_GRAD_SCRATCH)
+            if served is not None:
+                return served
         return _Dispatch.apply(_TextureOp, filter_mode, boundary, tex, uv, None, None, None)
     wrapper, levels = None, []
     if mip is None:
@@ -614,6 +621,11 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="aut
             levels = mip
         else:
             wrapper = mip
+    if host is not None and not levels and wrapper.mip is not None:
+        served = host.texture(tex, uv, uv_da, mip_level_bias, wrapper.mip, wrapper.max_mip_level, wrapper.texture_size, wrapper.cube_mode,
+                              _FILTER_MODES[filter_mode], boundary, _plugin._TEX_GRAD_SCRATCH)
+        if served is not None:
+            return served
     return _Dispatch.apply(_TextureOp, filter_mode, boundary, tex, uv, uv_da, mip_level_bias, wrapper, *levels)
 
 
@@ -649,6 +661,11 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
         topology_hash = _plugin.antialias_construct_topology_hash(tri)
     else:
         assert isinstance(topology_hash, _plugin.TopologyHashWrapper)
+    host = _plugin.host_layer()                             # (see _rasterize_layer)
+    if host is not None and topology_hash.ev_hash is not None:
+        served = host.antialias(color, rast, pos, tri, topology_hash.ev_hash, float(pos_gradient_boost))
+        if served is not None:
+            return served
     return _Dispatch.apply(_AntialiasOp, color, rast, pos, tri, topology_hash, pos_gradient_boost)
 
 

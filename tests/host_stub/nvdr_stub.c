@@ -99,3 +99,62 @@ int nvdr_interpolate_rasterize_grad(const float* attr, const float* rast, const 
     if (gd && !g_rast_db) free(gd);
     return rc;
 }
+
+/* ---- texture / antialias (the same contracts: gradients are added into zero-filled buffers) ---- */
+enum { C_TEX_FWD = 6, C_TEX_GRAD = 7 };
+
+int nvdr_texture_mip_info(int tex_n, int tex_h, int tex_w, int C, int cube, int max_mip_level, int* lw, int* lh, int64_t* off, int64_t* total) {
+    return nvdro_texture_mip_info(tex_n, tex_h, tex_w, C, cube, max_mip_level, lw, lh, off, total);
+}
+
+int nvdr_texture_construct_mip(const float* tex, int tex_n, int tex_h, int tex_w, int C, int cube, int max_mip_level, float* mip, nvdrStream_t stream) {
+    int lw[17], lh[17]; int64_t off[17], total;
+    (void)stream;
+    int L = nvdro_texture_mip_info(tex_n, tex_h, tex_w, C, cube, max_mip_level, lw, lh, off, &total);
+    if (L < 0) return NVDR_ERR_ARG;
+    return nvdro_texture_build_mip(tex, tex_n, tex_h, tex_w, C, cube, L, mip);
+}
+
+int nvdr_texture_fwd(const float* tex, const float* const* mip_ptrs, int L, const float* uv, const float* uv_da, const float* bias,
+                     int tex_n, int tex_h, int tex_w, int C, int N, int H, int W, int filter, int boundary, float* out,
+                     const uint8_t* tile_flags, nvdrStream_t stream) {
+    (void)tile_flags; (void)stream;
+    g_calls[C_TEX_FWD]++;
+    return nvdro_texture_fwd(tex, mip_ptrs, L, uv, uv_da, bias, tex_n, tex_h, tex_w, C, N, H, W, filter, boundary, out);
+}
+
+size_t nvdr_texture_grad_scratch_bytes(int N, int H, int W, int C) { (void)N; (void)H; (void)W; (void)C; return 64; }
+
+int nvdr_texture_grad(const float* tex, const float* const* mip_ptrs, int L, const float* uv, const float* uv_da, const float* bias,
+                      const float* dy, int tex_n, int tex_h, int tex_w, int C, int N, int H, int W, int filter, int boundary,
+                      int pull_mip_grads, float* g_tex, float* const* g_mip_ptrs, float* g_uv, float* g_uv_da, float* g_bias,
+                      void* scratch, size_t scratch_bytes, const uint8_t* tile_flags, nvdrStream_t stream) {
+    (void)scratch; (void)scratch_bytes; (void)tile_flags; (void)stream;
+    const size_t nt = (size_t)tex_n * (boundary == 0 ? 6 : 1) * tex_h * tex_w * C;
+    float* g = zeros(nt);
+    g_calls[C_TEX_GRAD]++;
+    int rc = nvdro_texture_grad(tex, mip_ptrs, L, uv, uv_da, bias, dy, tex_n, tex_h, tex_w, C, N, H, W, filter, boundary, pull_mip_grads,
+                                g, g_mip_ptrs, g_uv, g_uv_da, g_bias);
+    for (size_t i = 0; i < nt; i++) g_tex[i] += g[i];
+    free(g);
+    return rc;
+}
+
+int nvdr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const void* hash, size_t hash_bytes,
+                       int instance_mode, int N, int V, int T, int H, int W, int C, float* out, void* work, size_t work_bytes,
+                       const uint8_t* tile_flags, nvdrStream_t stream) {
+    (void)hash; (void)hash_bytes; (void)work; (void)work_bytes; (void)tile_flags; (void)stream;
+    return nvdro_antialias_fwd(color, rast, pos, tri, instance_mode, N, V, T, H, W, C, out);
+}
+
+int nvdr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy, const void* work,
+                        size_t work_bytes, int instance_mode, int N, int V, int T, int H, int W, int C, float* g_color, float* g_pos,
+                        nvdrStream_t stream) {
+    (void)work; (void)work_bytes; (void)stream;
+    const size_t np = (size_t)(instance_mode ? N : 1) * V * 4;
+    float* g = zeros(np);
+    int rc = nvdro_antialias_grad(color, rast, pos, tri, dy, instance_mode, N, V, T, H, W, C, g_color, g);
+    for (size_t i = 0; i < np; i++) g_pos[i] += g[i];
+    free(g);
+    return rc;
+}

@@ -281,9 +281,7 @@ def test_shared_bins_stress_with_poisoned_exchange_buffers(dr, oracle):
     bad = 0
     for it in range(200):
         pos, tri, want = scenes[it % 4]
-        if ctx.cpp_wrapper.scratch is not None:
-            ctx.cpp_wrapper.scratch.zero_()
-            ctx.cpp_wrapper.clean_layout = None
+        ctx.cpp_wrapper.poison_scratch(0)
         with torch.cuda.stream(side):
             for _ in range(it % 5):
                 noise.add_(1.0)

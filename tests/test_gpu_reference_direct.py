@@ -228,14 +228,14 @@ def test_growing_clip_pool_gives_the_same_image(dr, oracle, capfd):
     _plugin.set_log_level(0)
     try:
         ctx = dr.RasterizeCudaContext()
-        ctx.cpp_wrapper.pools[(2, T)] = 64                       # start far too small
+        ctx.cpp_wrapper.set_pool_hint(2, T, 64)                  # start far too small
         r, _ = dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))
         assert (r.cpu().numpy()[..., 3] != ro[..., 3]).sum() == 0
-        grown = ctx.cpp_wrapper.pools[(2, T)]
+        grown = ctx.cpp_wrapper.pool_slots(2, T)
         assert 64 < grown <= 6 * T
         assert "Clip pool grown" in capfd.readouterr().err
         r2, _ = dr.rasterize(ctx, _t(pos), _t(tri), (96, 128))    # second call: the remembered size fits at once
-        assert torch.equal(r, r2) and ctx.cpp_wrapper.pools[(2, T)] == grown
+        assert torch.equal(r, r2) and ctx.cpp_wrapper.pool_slots(2, T) == grown
         assert "Clip pool grown" not in capfd.readouterr().err
         t_pos, t_tri = _t(pos), _t(tri)
         with pytest.raises(RuntimeError, match="cannot be captured"):
@@ -253,6 +253,7 @@ def test_growing_pool_mode_with_the_worst_case_pool_does_not_read_garbage(dr, or
     clears nor writes in that case, so a stale value above the pool made the retry loop spin for ever.  The buffer is
     poisoned first so that a read of the counter would see such a value."""
     from nvdiffrast_amd import _capi
+    from nvdiffrast_amd.torch import _plugin
     rng = np.random.default_rng(13)
     T = 500
     pos = rng.normal(size=(3, 3 * T, 4)).astype(np.float32) * np.array([3.0, 3.0, 1.5, 1.0], np.float32)
@@ -268,6 +269,8 @@ def test_growing_pool_mode_with_the_worst_case_pool_does_not_read_garbage(dr, or
         assert st.pool_hint(3, T) == 6 * T
         nbytes = st.scratch_bytes(lib, 3, T, 64, 64, 6 * T)
         st.scratch = torch.full((nbytes,), 0x7F, dtype=torch.uint8, device="cuda")      # every int reads 0x7F7F7F7F
+        if _plugin.host_layer() is not None:
+            st.host_state(_plugin.host_layer()).set_scratch(torch.full((nbytes,), 0x7F, dtype=torch.uint8, device="cuda"))
         for _ in range(2):
             r, _ = dr.rasterize(ctx, _t(pos), _t(tri), (64, 64))
             assert (r.cpu().numpy()[..., 3] != ro[..., 3]).sum() == 0
@@ -276,7 +279,7 @@ def test_growing_pool_mode_with_the_worst_case_pool_does_not_read_garbage(dr, or
         pos2 = rng.normal(size=(1, 3 * T2, 4)).astype(np.float32) * np.array([3.0, 3.0, 1.5, 1.0], np.float32)
         pos2[..., 3] = rng.uniform(0.05, 1.5, size=pos2.shape[:2])
         tri2 = np.arange(3 * T2, dtype=np.int32).reshape(T2, 3)
-        st.pools[(1, T2)] = 6 * T2
+        st.set_pool_hint(1, T2, 6 * T2)
         ro2, _ = oracle.rasterize(pos2, tri2, (64, 64))
         r2, _ = dr.rasterize(ctx, _t(pos2), _t(tri2), (64, 64))
         assert (r2.cpu().numpy()[..., 3] != ro2[..., 3]).sum() == 0

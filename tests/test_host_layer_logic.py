@@ -29,7 +29,8 @@ from nvdiffrast_amd.utils import m10k_batch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SYMBOLS = ("nvdr_last_error", "nvdr_get_option", "nvdr_log", "nvdr_rasterize_scratch_bytes_pool", "nvdr_rasterize_pool_peak_offset",
            "nvdr_tile_flags_bytes", "nvdr_rasterize_fwd", "nvdr_rasterize_grad", "nvdr_interpolate_fwd", "nvdr_interpolate_grad",
-           "nvdr_interpolate_rasterize_grad")
+           "nvdr_interpolate_rasterize_grad", "nvdr_texture_mip_info", "nvdr_texture_construct_mip", "nvdr_texture_fwd",
+           "nvdr_texture_grad", "nvdr_texture_grad_scratch_bytes", "nvdr_antialias_fwd", "nvdr_antialias_grad")
 C_RAST_FWD, C_RAST_GRAD, C_INTERP_FWD, C_INTERP_GRAD, C_FUSED, C_CLEAN = range(6)
 
 
@@ -409,3 +410,87 @@ def test_clean_scratch_flag_and_declined_calls(host, dr):
         assert m.interpolate(attr, rast, tri, None, False, []) is None                  # the checking mode is the Python layer's
     finally:
         m.set_verify(False)
+
+
+@pytest.mark.parametrize("mode", ["linear-mipmap-linear", "linear-mipmap-nearest", "linear", "nearest", "bias-only", "cube"])
+def test_texture_and_antialias_through_the_compiled_layer(host, dr, mode):
+    """The full pipeline of config 3 on the CPU stub: every forward value and every gradient equals the oracle's chain."""
+    m, lib = host
+    b, res, G = _scene(seed=47)
+    ctx = _Ctx(dr)
+    rng = np.random.default_rng(4)
+    V = b["pos"].shape[1]
+    cube = mode == "cube"
+    uvattr = (rng.normal(size=(V, 3)) if cube else rng.uniform(0, 1, size=(V, 2))).astype(np.float32)
+    tex_np = rng.uniform(size=(1, 6, 16, 16, 3) if cube else (1, 32, 16, 3)).astype(np.float32)
+    pos, uva, tex, tri = _t(b["pos"], True), _t(uvattr, True), _t(tex_np, True), _t(b["tri"])
+    n = b["pos"].shape[0]
+    bias_np = rng.uniform(0, 2, size=(n,) + res).astype(np.float32)
+    bias = _t(bias_np, True)
+    f0, g0 = lib.nvdr_stub_calls(6), lib.nvdr_stub_calls(7)
+    rast, rast_db = dr.rasterize(ctx, pos, tri, res)
+    uv, uv_da = dr.interpolate(uva, rast, tri, rast_db=rast_db, diff_attrs="all")
+    kw = dict(boundary_mode="cube" if cube else "wrap")
+    if mode in ("linear", "nearest"):
+        col = dr.texture(tex, uv, filter_mode=mode, **kw)
+    elif mode == "bias-only":
+        col = dr.texture(tex, uv, mip_level_bias=bias, filter_mode="linear-mipmap-linear", **kw)
+    elif cube:
+        col = dr.texture(tex, uv, uv_da, filter_mode="linear-mipmap-linear", **kw)
+    else:
+        col = dr.texture(tex, uv, uv_da, mip_level_bias=bias, filter_mode=mode, **kw)
+    assert col.grad_fn.name() == "NvdrTextureBackward"
+    from nvdiffrast_amd.torch import _plugin
+    topo = _plugin.TopologyHashWrapper()
+    topo.ev_hash = torch.zeros(16, dtype=torch.int32)       # (built on the GPU by the product; the stub's oracle has its own edge map)
+    aa = dr.antialias(col, rast, pos, tri, topology_hash=topo, pos_gradient_boost=2.0)
+    assert aa.grad_fn.name() == "NvdrAntialiasBackward"
+    dy = rng.normal(size=tuple(aa.shape)).astype(np.float32)
+    aa.backward(_t(dy))
+    assert (lib.nvdr_stub_calls(6), lib.nvdr_stub_calls(7)) == (f0 + 1, g0 + 1)
+    # the oracle's chain on the same inputs
+    ro, rdbo = oracle.rasterize(b["pos"], b["tri"], res)
+    uvo, uvdao = oracle.interpolate(uvattr, ro, b["tri"], rast_db=rdbo, diff_attrs="all")
+    okw = dict(boundary_mode="cube" if cube else "wrap")
+    if mode in ("linear", "nearest"):
+        okw.update(filter_mode=mode)
+    elif mode == "bias-only":
+        okw.update(mip_level_bias=bias_np, filter_mode="linear-mipmap-linear")
+    elif cube:
+        okw.update(uv_da=uvdao, filter_mode="linear-mipmap-linear")
+    else:
+        okw.update(uv_da=uvdao, mip_level_bias=bias_np, filter_mode=mode)
+    colo = oracle.texture(tex_np, uvo, **okw)
+    aao = oracle.antialias(colo, ro, b["pos"], b["tri"])
+    _close(col, colo, "col"); _close(aa, aao, "aa")
+    g_col, g_pos_aa = oracle.antialias_grad(colo, ro, b["pos"], b["tri"], dy)
+    tg = oracle.texture_grad(tex_np, uvo, g_col, **okw)
+    g_tex, g_uv, g_uv_da, g_bias = tg["tex"], tg["uv"], tg["uv_da"], tg["mip_level_bias"]
+    _close(tex.grad, g_tex, "g_tex")
+    if mode not in ("nearest",):
+        ga, gr, grdb = oracle.interpolate_grad(uvattr, ro, b["tri"], g_uv, rast_db=rdbo,
+                                                dda=(g_uv_da if g_uv_da is not None else np.zeros_like(uvdao)), diff_attrs="all")
+        gp = oracle.rasterize_grad(b["pos"], b["tri"], ro, gr, grdb) + 2.0 * g_pos_aa
+        _close(uva.grad, ga, "g_uvattr"); _close(pos.grad, gp, "g_pos")
+    else:
+        assert uva.grad is None
+        _close(pos.grad, 2.0 * g_pos_aa, "g_pos (antialias only)")
+    if mode in ("bias-only", "linear-mipmap-linear"):
+        _close(bias.grad, g_bias, "g_bias")
+
+
+def test_texture_declines_what_it_does_not_serve(host, dr):
+    m, lib = host
+    rng = np.random.default_rng(5)
+    tex, uv = _t(rng.uniform(size=(1, 8, 8, 3)).astype(np.float32)), _t(rng.uniform(size=(1, 4, 4, 2)).astype(np.float32))
+    assert m.texture(tex, uv, None, None, None, 0, [], False, 1, 1, True) is not None
+    assert m.texture(tex.double(), uv, None, None, None, 0, [], False, 1, 1, True) is None
+    assert m.texture(tex, uv[..., :1], None, None, None, 0, [], False, 1, 1, True) is None
+    assert m.texture(tex, uv, None, None, None, 0, [], False, 3, 1, True) is None                 # mipmapped without uv_da / bias / mip
+    mip = m.construct_mip(tex, -1, False)
+    assert mip is not None and mip.numel() == 3 * (16 + 4 + 1)
+    uv_da = _t(np.zeros((1, 4, 4, 4), np.float32))
+    assert m.texture(tex, uv, uv_da, None, mip, -1, [1, 8, 8, 3], False, 3, 1, True) is not None
+    assert m.texture(tex, uv, uv_da, None, mip, -1, [1, 8, 8, 4], False, 3, 1, True) is None      # wrapper made for another texture
+    assert m.texture(tex, uv, uv_da, None, mip[:-1], -1, [1, 8, 8, 3], False, 3, 1, True) is None
+    assert m.construct_mip(_t(np.zeros((1, 6, 8, 3), np.float32)), -1, False) is None               # odd extent above 1: the Python layer words it
