@@ -71,7 +71,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 XGMI_LINK_GBS = 153.0          # per direction per link; 7 links per GPU, fully connected (task statement / SURVEY 8e)
-HOST_MS_PER_CHUNK = 0.20       # measured host cost of issuing one chunk's six launches eagerly
+HOST_MS_PER_CHUNK = 0.07       # measured host cost of issuing one chunk's six launches eagerly (compiled host layer: DESIGN 5; 0.20 through round 5)
+COPY_GBS = 5400.0              # streaming copy rate of one MI355X (tools/write_bw.py: read + write), prices the image-packing pass
 TRIANGLES = 10000
 
 WORKLOADS = {
@@ -233,11 +234,16 @@ def plan_chunks(n_items, item_bytes, compute_ms, links):
                      "predicted_step_ms_by_chunks": table}
 
 
-def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduce_ms=0.03, gather_every=(4, 8)):
+def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduce_ms=0.03, gather_every=(4, 8), channels=4):
     """What the 1/2/4/8-GPU curve must look like from the link arithmetic alone: whole-job speed-up over
     one GPU with the image all-gather inside the step (every rank receives (N-1) x its own image bytes, one peer per
     link: floor = own bytes / 153 GB/s, whatever N) and without it (independent ranks + one small all-reduce)."""
+    from nvdiffrast_amd.parallel import payload_bytes_per_pixel
+    fmts = ("f32", "f16", "rgba8", "rgb8")
     out = {"with_image_gather": {}, "without_image_gather": {}, **{"gather_every_%d" % k: {} for k in gather_every},
+           # the per-step gather as the default line runs it: packed on the producing rank (one more streaming pass over the image:
+           # 4 + b bytes per value at the copy rate), collected one step later -- a step takes max(kernels + pack, link time)
+           "pipelined_per_step_gather": {f: {} for f in fmts},
            "assumes": "compute = %.4f ms per item (this run), "
            "xGMI link %.0f GB/s at 100 %% efficiency, %.0f us for the shared-gradient all-reduce" % (ms_per_item, XGMI_LINK_GBS, allreduce_ms * 1e3)}
     items1 = per_gpu if scaling == "weak" else total
@@ -251,6 +257,11 @@ def predicted_scaling(ms_per_item, scaling, per_gpu, total, item_bytes, allreduc
         c, _ = plan_chunks(items, item_bytes, C, n - 1)
         t_g = max(C, c * HOST_MS_PER_CHUNK if n > 1 else 0.0, (max(C / (2 * c), HOST_MS_PER_CHUNK / 2) + G) if n > 1 else C) + ar
         t_n = C + ar
+        for f in fmts:
+            frac = payload_bytes_per_pixel(f, channels) / (4.0 * channels)
+            pack = 0.0 if f == "f32" else items * item_bytes * (1 + frac) / (COPY_GBS * 1e9) * 1e3
+            t_p = (max(C + pack, G * frac) + ar) if n > 1 else C
+            out["pipelined_per_step_gather"][f][str(n)] = round((job_items / t_p) / (items1 / t1), 2)
         out["with_image_gather"][str(n)] = round((job_items / t_g) / (items1 / t1), 2)
         out["without_image_gather"][str(n)] = round((job_items / t_n) / (items1 / t1), 2)
         for k in gather_every:
@@ -276,7 +287,8 @@ class DryKernels:
 class Job:
     """One workload on this rank: its tensors resident in device memory and the step the timed region repeats."""
 
-    def __init__(self, name, N, total_items, first, rank, world, dev, dry, res, distributed, chunks, gather, gather_every=1):
+    def __init__(self, name, N, total_items, first, rank, world, dev, dry, res, distributed, chunks, gather, gather_every=1,
+                 gather_format="f32", gather_pipelined=False):
         import torch.distributed as dist
         from nvdiffrast_amd.parallel import broadcast_shared
         self.dist = dist
@@ -291,6 +303,9 @@ class Job:
         self.scene_name = self.wl.get("scene", "m10k")
         self.scene = build_scene(self.scene_name, N, self.A, dry, rank)
         self.gather_every = max(1, int(gather_every))
+        self.gather_format = gather_format
+        self.last_batch = None
+        self.set_gather_mode(gather_format, gather_pipelined)
         self.step_index = 0
         self.in_flight = []          # image gathers of earlier steps that may still be running (gather_every > 1)
         self.literal = False         # step variant: SURVEY 8(d)'s literal `(out*G).sum().backward()`
@@ -325,6 +340,15 @@ class Job:
         self.set_chunks(chunks)
         self.last_rast = None
 
+    def set_gather_mode(self, fmt, pipelined):
+        """What the image all-gather carries and when its result is waited for (nvdiffrast_amd/parallel.py ImageGather)."""
+        from nvdiffrast_amd.parallel import ImageGather
+        self.gather_format = fmt
+        self.pipe = None
+        if pipelined and self.gather_every == 1:
+            n_items = self.total_items if self.wl["total"] is not None else None       # (strong scaling: the split may be ragged)
+            self.pipe = ImageGather(fmt, n_items=n_items, pipelined=True)
+
     def set_chunks(self, chunks):
         """The rank's items are rendered in this many calls (chunks exist to overlap a chunk's image all-gather with the next
         chunk's kernels; without the gather one call is best: larger launches, and the rasterizer's work order needs 2048 bins)."""
@@ -348,7 +372,7 @@ class Job:
         return dr.antialias(col, rast, p, self.tri, topology_hash=self.topo), rast
 
     def step(self):
-        from nvdiffrast_amd.parallel import allreduce_shared_grads, gather_items_async
+        from nvdiffrast_amd.parallel import allreduce_shared_grads, start_image_gather
         self.pos.grad = None
         self.shared.grad = None
         if self.full:
@@ -368,12 +392,15 @@ class Job:
         for c, (a, b) in enumerate(self.bounds):
             p = self.pos if self.chunks == 1 else self.pos[a:b]
             out, rast = self.render(p)
-            if gather_now:
+            if gather_now and self.pipe is not None:
+                # packed on this rank, all-gathered on RCCL's own stream; collected at the end of the NEXT step
+                self.pipe.submit(out.detach())
+            elif gather_now:
                 # the collective runs on RCCL's own stream, ordered after this chunk's kernels; the next chunk's
                 # kernels are issued right away and overlap it
-                src = out.detach()
-                work, self.gathered[c] = gather_items_async(src, out=self.gathered[c])
-                pending.append((work, src))
+                h = start_image_gather(out.detach(), self.gather_format, recv=self.gathered[c])
+                self.gathered[c] = h.recv
+                pending.append((h, None))
             if self.literal:
                 (out * (self.G if self.chunks == 1 else self.G[a:b])).sum().backward()
             else:
@@ -381,6 +408,8 @@ class Job:
             self.last_rast = rast
         if self.distributed:
             allreduce_shared_grads([self.shared] + ([self.tex] if self.full else []))
+        if gather_now and self.pipe is not None:
+            self.last_batch = self.pipe.collect()         # the previous step's complete batch (its link time ran behind this step's kernels)
         if self.gather_every > 1:
             self.in_flight += pending
         else:
@@ -391,6 +420,10 @@ class Job:
         for w, _keep in self.in_flight:
             w.wait()
         self.in_flight = []
+        if self.pipe is not None:
+            left = self.pipe.drain()
+            if left:
+                self.last_batch = left[-1]
 
     def fence(self):
         if not self.dry:
@@ -722,6 +755,12 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1: all-gather the output images of every k-th step only, overlapped with the following steps (default 1 = "
                          "every step, the number the metric is quoted on; k = 4 is the schedule the link arithmetic predicts to scale >= 6x)")
+    ap.add_argument("--gather-format", choices=["f32", "f16", "rgba8", "rgb8"], default="rgb8",
+                    help="N > 1: what the per-step image all-gather carries (nvdiffrast_amd/parallel.py): f32 as rendered, f16, rgba8 = every "
+                         "channel as unorm8, rgb8 = the first three channels as unorm8 (default: the per-step gather the xGMI links can carry)")
+    ap.add_argument("--no-gather-pipeline", action="store_true",
+                    help="N > 1: wait for a step's images inside that step (default: collect them at the end of the NEXT step, so the "
+                         "link time hides behind its kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="default run: do not also measure BASELINE configs[1], [2], [4]")
     ap.add_argument("--cpu-items", type=int, default=64, help="items in the CPU-oracle sample")
@@ -790,12 +829,20 @@ def main():
     est_ms_per_item = (0.0080 if wl["graph"] == "ri" else 0.105) * (RES * RES) / (wl["res"] * wl["res"])
     n_max = -(-total_items // world)
     chunks, chunk_plan = plan_chunks(n_max, item_bytes, n_max * est_ms_per_item, (world - 1) if gather else 0)
+    chunk_plan_chunks = chunks                                     # (for the f32-in-step comparison leg)
     if args.chunks:
         chunks = args.chunks
     if not gather:
         chunks = args.chunks or 1
+    # The default exchange: packed images (--gather-format), collected one step later -- the whole next step to hide behind, so
+    # the rank's items are rendered in one call.  --no-gather-pipeline / --gather-every k keep the chunked overlap inside the step.
+    # An explicit --chunks > 1 asks for the overlap inside the step, i.e. no pipelining.
+    pipelined = gather and not args.no_gather_pipeline and args.gather_every == 1 and not (args.chunks and args.chunks > 1)
+    if pipelined:
+        chunks = 1
 
-    job = Job(args.workload, N, total_items, first, rank, world, dev, dry, RES, distributed, chunks, gather, args.gather_every)
+    job = Job(args.workload, N, total_items, first, rank, world, dev, dry, RES, distributed, chunks, gather, args.gather_every,
+              gather_format=args.gather_format if gather else "f32", gather_pipelined=pipelined)
 
     run = job.step
     if args.graph:
@@ -824,22 +871,39 @@ def main():
     # same job without it next to `value`, and the link arithmetic, so that the two effects can be told apart.
     collective = None
     if distributed:
+        from nvdiffrast_amd.parallel import payload_bytes_per_pixel, payload_channels
         ms_ng = ms_per_step
+        ms_f32 = None
         if gather:
             planned = job.chunks
             job.drain()
             job.gather_on = False
             job.set_chunks(1)                                     # (nothing to overlap: the rank's items in one call)
             host_ng, evt_ng = job.timed_windows(run, min(args.warmup, 2), args.steps, max(1, min(args.windows, 3)))
-            job.set_chunks(planned)
             job.gather_on = True
             ms_ng, _ = window_stats(host_ng, evt_ng, args.steps)
-        img_bytes = N * item_bytes
+            if args.gather_format != "f32" or pipelined:
+                # ... and the same job with the images gathered as rendered (f32), waited for inside the step, chunked to overlap:
+                # what the default line of rounds 2-5 measured
+                job.set_gather_mode("f32", False)
+                job.set_chunks(chunk_plan_chunks)
+                host_f, evt_f = job.timed_windows(run, min(args.warmup, 2), args.steps, max(1, min(args.windows, 3)))
+                ms_f32, _ = window_stats(host_f, evt_f, args.steps)
+                job.drain()
+                job.set_gather_mode(args.gather_format, pipelined)
+            job.set_chunks(planned)
+        fmt = args.gather_format if gather else "f32"
+        img_bytes = N * RES * RES * payload_bytes_per_pixel(fmt, C_out)
         links = world - 1                                         # fully connected xGMI: one link per peer (0: a forced group of one)
         collective = {
             "image_gather_in_step": bool(gather),
+            "gather_format": fmt if gather else None,
+            "gather_payload": ("%d of %d channels, %d byte(s) each" % (payload_channels(fmt, C_out), C_out, payload_bytes_per_pixel(fmt, C_out) // payload_channels(fmt, C_out))) if gather else None,
+            "gather_pipelined": bool(pipelined),                  # a step's images are collected at the end of the next step
             "image_bytes_sent_per_rank_per_step": img_bytes * links if gather else 0,
             "image_bytes_received_per_rank_per_step": img_bytes * links if gather else 0,
+            "ms_per_step_with_f32_gather_in_step": None if ms_f32 is None else round(ms_f32, 4),
+            "value_with_f32_gather_in_step": None if ms_f32 is None else round(total_items * RES * RES / (ms_f32 * 1e-3) / 1e6, 1),
             "xgmi_links_per_gpu_used": links, "xgmi_link_gbs": XGMI_LINK_GBS,
             # every link carries one rank's images, all links in parallel: the floor does not shrink with more GPUs
             "xgmi_floor_ms": round(img_bytes / (XGMI_LINK_GBS * 1e9) * 1e3, 4) if links else None,
@@ -847,7 +911,8 @@ def main():
             "value_without_image_gather": round(total_items * RES * RES / (ms_ng * 1e-3) / 1e6, 1),
             "chunks": job.chunks, "chunk_plan": chunk_plan, "gather_every": job.gather_every,
             # the curve the link arithmetic predicts, from THIS run's compute time per item (gather-free step / items)
-            "predicted_scaling": predicted_scaling(ms_ng / max(N, 1), wl["scaling"], wl["per_gpu"] or N, wl["total"] or total_items, item_bytes),
+            "predicted_scaling": predicted_scaling(ms_ng / max(N, 1), wl["scaling"], wl["per_gpu"] or N, wl["total"] or total_items, item_bytes,
+                                                   channels=C_out),
         }
 
     P_total = total_items * RES * RES
@@ -886,9 +951,11 @@ def main():
                "batch_per_gpu": N, "total_items": total_items, "resolution": [RES, RES], "triangles": int(job.tri.shape[0]),
                "coverage": coverage, "tile_coverage": tile_cov,
                "parallelism": "dp%d (items sharded; per step: %sall-reduce of the shared-input gradients)"
-                              % (world, ("all-gather of the output images%s in %d chunks overlapped with rendering, "
-                                         % (" of every %d-th step" % job.gather_every if job.gather_every > 1 else "", job.chunks)) if gather else ""),
+                              % (world, (("all-gather of the output images as %s, collected one step later, " % job.gather_format) if job.pipe is not None
+                                         else "all-gather of the output images%s as %s in %d chunks overlapped with rendering, "
+                                         % (" of every %d-th step" % job.gather_every if job.gather_every > 1 else "", job.gather_format, job.chunks)) if gather else ""),
                "chunks": job.chunks, "gather_images": bool(gather), "gather_every": job.gather_every,
+               "gather_format": job.gather_format if gather else None, "gather_pipelined": job.pipe is not None,
                "launch": "hipGraph replay" if args.graph else "eager"}
         # ---- the other BASELINE configs and the regimes the benchmark scene hides: same process, single GPU, default run only ---
         if (not dry and world == 1 and not distributed and args.workload == "ch" and args.batch is None and args.res is None
@@ -928,7 +995,10 @@ def main():
         if dry:
             result["dry_run"] = True
             result["backend"] = "gloo" if distributed else "none"
-            if gather:
+            if gather and job.pipe is not None:
+                result["gathered_rows_total"] = int(job.last_batch.shape[0])          # the last step's complete batch, as collected
+                result["gathered_payload"] = [str(job.last_batch.dtype).replace("torch.", ""), int(job.last_batch.shape[-1])]
+            elif gather:
                 g0 = job.gathered[0]
                 result["gathered_rows_chunk0"] = int(g0.shape[0])
                 result["gathered_rows_total"] = int(sum(g.shape[0] for g in job.gathered))
@@ -1045,7 +1115,7 @@ def compact_line(full, detail_path):
     out["collective"] = full.get("collective")
     cf = full.get("configs")
     out["configs"] = None if cf is None else {k: compact_config(v) for k, v in cf.items()}
-    for k in ("dry_run", "backend", "gathered_rows_chunk0", "gathered_rows_total"):
+    for k in ("dry_run", "backend", "gathered_rows_chunk0", "gathered_rows_total", "gathered_payload"):
         if k in full:
             out[k] = full[k]
     out["detail"] = None if not detail_path else os.path.basename(detail_path)

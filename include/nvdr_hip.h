@@ -46,7 +46,7 @@ int         nvdr_abi_version(void);
  *                            its loss of the corner flag for texture slices >= 1 (texture_kernel.cu:85-88,431-432);
  *                            1: the missing corner texel is the average of the other three for every slice.
  *  NVDR_OPT_SCRATCH_LIMIT_MB rasterizer scratch policy of the HOST GLUE (the library itself never allocates): up to this
- *                            many MiB (default 1024) the glue reserves the worst case -- 6 extra record slots per
+ *                            many MiB (default 4096: 1.4 % of the MI355X's 288 GB; batch 256 of a 10 k-triangle mesh needs 1.2 GiB) the glue reserves the worst case -- 6 extra record slots per
  *                            triangle for the clipper -- so that nothing can overflow and no call ever synchronises
  *                            the host; above it, it starts from a small clip pool, reads the pool demand back after
  *                            each call (one host synchronisation, as the reference does every call,
@@ -238,6 +238,19 @@ int nvdr_antialias_grad(const float* color, const float* rast, const float* pos,
                         const float* dy, const void* work, size_t work_bytes,
                         int instance_mode, int N, int V, int T, int H, int W, int C,
                         float* g_color, float* g_pos, nvdrStream_t stream);
+
+/* ---- output images for the xGMI links --------------------------------------------------------------------------
+ * Not entry points of the reference (it has no multi-GPU path, docs/index.html:758-759): north_star's 8-GPU layout all-gathers
+ * the per-item output images every step, and an f32 image is 4x what a consumer of rendered images needs.  nvdr_image_pack
+ * converts an image of `pixels` pixels with `channels_in` f32 channels each on the producing rank: the first `channels_out`
+ * channels of every pixel (an RGB image out of RGBA / four attributes), as NVDR_IMAGE_UNORM8: round(clamp(x, 0, 1) * 255)
+ * (round-half-even, NaN -> 0), one byte each; NVDR_IMAGE_F16: round-to-nearest-even halves; NVDR_IMAGE_F32: the selected
+ * channels as they are.  nvdr_image_unpack is the inverse for `count` packed values (q / 255; exact widening) for a receiver
+ * that wants f32 again.  Buffers 16-byte aligned; nvdr_image_packed_bytes(pixels * channels_out, format) sizes `dst`. */
+enum { NVDR_IMAGE_F32 = 0, NVDR_IMAGE_F16 = 1, NVDR_IMAGE_UNORM8 = 2 };
+size_t nvdr_image_packed_bytes(size_t count, int format);
+int nvdr_image_pack(const float* src, void* dst, size_t pixels, int channels_in, int channels_out, int format, nvdrStream_t stream);
+int nvdr_image_unpack(const void* src, float* dst, size_t count, int format, nvdrStream_t stream);
 
 #ifdef __cplusplus
 }

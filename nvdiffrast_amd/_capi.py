@@ -17,7 +17,8 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 _vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
-ABI_VERSION = 7            # include/nvdr_hip.h; 2: scratch_clean; 3: options + log; 4: caller-chosen clip pool; 5: fused backward, texture_grad scratch; 6: tile flags; 7: work order behind the flags
+ABI_VERSION = 8            # include/nvdr_hip.h; 2: scratch_clean; 3: options + log; 4: caller-chosen clip pool; 5: fused backward, texture_grad scratch; 6: tile flags; 7: work order behind the flags; 8: image pack / unpack
+IMAGE_F32, IMAGE_F16, IMAGE_UNORM8 = 0, 1, 2
 OPT_LOG_LEVEL, OPT_CUBE_CORNER_FIX, OPT_SCRATCH_LIMIT_MB = 0, 1, 2
 c_longlong = ctypes.c_longlong
 
@@ -56,6 +57,9 @@ SIGNATURES = {
     "nvdr_texture_grad": (c_int, [c_void_p, _vpp, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_void_p, _vpp, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "nvdr_image_packed_bytes": (c_size_t, [c_size_t, c_int]),
+    "nvdr_image_pack": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p]),
+    "nvdr_image_unpack": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "nvdr_antialias_hash_bytes": (c_size_t, [c_int]),
     "nvdr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "nvdr_antialias_construct_topology_hash": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),

@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static int g_options[NVDR_OPT_COUNT] = {1 /* WARNING */, 0, 1024 /* MiB */};
+static int g_options[NVDR_OPT_COUNT] = {1 /* WARNING */, 0, 4096 /* MiB */};
 int get_option(int option) { return (option >= 0 && option < NVDR_OPT_COUNT) ? g_options[option] : 0; }
 
 struct Timed { const char* name; hipEvent_t a, b; };
@@ -90,7 +90,7 @@ void profile_end(hipStream_t s) {
 extern "C" {
 
 const char* nvdr_last_error(void) { return nvdr::g_err; }
-int nvdr_abi_version(void) { return 7; }
+int nvdr_abi_version(void) { return 8; }
 
 int nvdr_set_option(int option, int value) {
     if (option < 0 || option >= NVDR_OPT_COUNT) { nvdr::set_error("nvdr_set_option: unknown option %d", option); return NVDR_ERR_ARG; }

