@@ -466,7 +466,7 @@ def _attach_tiles(t, flags, kind):
             del _tile_registry[ptr]
     _tile_registry[ptr] = weakref.ref(t, _forget)
     h = host_layer()
-    if h is not None:
+    if h is not None and flags is not None:
         h.attach(t, flags, _KIND[kind])          # the compiled layer's registry (by storage): its interpolate() finds the flags too
 
 

@@ -306,7 +306,7 @@ def test_scratch_sizes_of_the_two_policies():
     assert lib.nvdr_rasterize_pool_peak_offset(N, T, 512, 512, pool) + 4 <= small
     assert st.pool_hint(2, 100) == 600                                   # small meshes: the complete worst case
     assert st.grow_pool(N, T, 400000) == 501024 and st.pool_hint(N, T) == 501024
-    assert lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB) == 1024
+    assert lib.nvdr_get_option(_capi.OPT_SCRATCH_LIMIT_MB) == 4096
 
 
 def test_compiled_call_layer_binds_the_table_and_agrees_with_ctypes():
