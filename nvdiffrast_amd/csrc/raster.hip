@@ -1544,7 +1544,9 @@ __global__ __launch_bounds__(kFineThreads) __attribute__((amdgpu_waves_per_eu(8,
         for (int tt = 0; tt < kTilesPerWave; tt++) {
             // (the array rests at all ones; an untouched pixel takes the kernel's own sentinel, kInit, like the pixels of every
             // other bin: the depth surface of a peeling pass then holds kDepthMax there, not 0xFFFFFFFF -- ADVICE r4)
-            sh.key[tileRow][tile0 + tt][laneS] = min(gkeys[tt * 64], kInit);           // (read again below by this same lane)
+            sh.key[tileRow][tile0 + tt][laneS] = min(gkeys[tt * 64], kInit);           // (read below by pixel column -- ANOTHER lane of this
+            //  same wave: LDS operations of one wave complete in order, so no barrier is needed while a wave shades only tiles it
+            //  wrote itself; a change to kWavesPerRow / kTilesPerWave that breaks that needs a __syncthreads() here)
             gkeys[tt * 64] = ~0ull;
         }
     }

@@ -86,6 +86,16 @@ static PyObject* bound_call(PyObject* self_, PyObject* const* args, size_t nargs
                 const unsigned long long v = PyLong_AsUnsignedLongLong(o);
                 if (v == (unsigned long long)-1 && PyErr_Occurred()) goto done;
                 a[i] = v;
+            } else if (PyIndex_Check(o)) {
+                /* an integer-like object (a numpy integer scalar): its VALUE -- never, through the branch below, the address of
+                   the host memory that holds it (ctypes raised TypeError here; a device pointer must not silently
+                   become a host address) */
+                PyObject* idx = PyNumber_Index(o);
+                if (!idx) goto done;
+                const unsigned long long v = PyLong_AsUnsignedLongLong(idx);
+                Py_DECREF(idx);
+                if (v == (unsigned long long)-1 && PyErr_Occurred()) goto done;
+                a[i] = v;
             } else {
                 /* a host array (ctypes array, bytes-like): its buffer's address */
                 if (c != 'p' || nviews == 4 || PyObject_GetBuffer(o, &views[nviews], PyBUF_SIMPLE) != 0) {
@@ -102,7 +112,12 @@ static PyObject* bound_call(PyObject* self_, PyObject* const* args, size_t nargs
         }
     }
     {
-        const u64 r = call_n(self->fn, (int)n, a);
+        /* the arguments are plain integers now and the buffer views are held until `done`: the native call runs without the
+           GIL, as it did under ctypes.CDLL (one thread per GPU, autograd's worker threads) */
+        u64 r;
+        Py_BEGIN_ALLOW_THREADS
+        r = call_n(self->fn, (int)n, a);
+        Py_END_ALLOW_THREADS
         if (self->ret == 'v') { result = Py_None; Py_INCREF(result); }
         else if (self->ret == 'n') result = PyLong_FromUnsignedLongLong(r);
         else result = PyLong_FromLong((long)(int32_t)r);

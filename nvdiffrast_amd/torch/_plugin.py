@@ -721,6 +721,14 @@ def _take_prepared(fn, pos, tri, out, dy, ddb, call):
     return None
 
 
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+
+
+def _in_backward():
+    """True while autograd's engine is running a backward pass on this thread."""
+    return _graph_task_id is not None and _graph_task_id() >= 0
+
+
 def rasterize_grad_db(pos, tri, out, dy, ddb, tile_flags=None):
     """torch_rasterize.cpp:171-256.  ``ddb`` may be None (== rasterize_grad).  ``dy`` may be None as well -- what a caller whose
     autograd function runs with set_materialize_grads(False) passes for an unused `rast`: only ddb's
@@ -914,7 +922,9 @@ def interpolate_grad_da(attr, rast, tri, dy, rast_db, dda, diff_attrs_all, diff_
     dda_ = dda.contiguous() if enable_da else None
     lst, nlst = _diff_list([] if diff_attrs_all else diff_attrs_vec)
     tile_flags = _auto_flags(fn, tile_flags, "rast", rast)
-    if fuse is None and _fused["mode"] == "auto":
+    # The exchange is armed only INSIDE an autograd backward pass: a direct call of this entry point -- a caller that
+    # wants g_rast's memory, a custom op reading data_ptr() -- gets the reference's three ordinary tensors.
+    if fuse is None and _fused["mode"] == "auto" and _in_backward():
         org = _origin_of(rast)
         if org is not None:
             org.pending = None             # left over from a backward pass that never reached rasterize_grad: void

@@ -116,3 +116,25 @@ def test_config3_full_size_properties(dr, headline):
     (g_col,) = torch.autograd.grad(out, col, G)
     expect = (g_col * cov[..., None]).double().sum((0, 1, 2))
     assert torch.allclose(g_tex.double().sum((0, 1, 2)), expect, rtol=2e-4, atol=5e-2)
+
+
+@pytest.mark.parametrize("name", ["t1m", "t1m_shuffled", "s10k_1024"])
+def test_million_triangle_scenes_equal_the_reference_fixture(dr, name):
+    """tests/golden/t1m_reference.npz: what the REFERENCE's own rasterizer (oracle/_ref; tests/golden/make_t1m_fixture.py) makes of
+    item 0 of bench.py's million-triangle scenes (per-bin triangle lists, SHADE launches) and of an S10k stress item at 1024^2.
+    The HIP path must give the same id image (SHA-256) and the same sampled barycentrics."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_t1m_fixture", os.path.join(here, "golden", "make_t1m_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    fx = np.load(os.path.join(here, "golden", "t1m_reference.npz"))
+    (pos, tri, res), = [(p, t, r) for n, p, t, r in mk.scenes() if n == name]
+    ctx = dr.RasterizeCudaContext()
+    rast, _ = dr.rasterize(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), res)
+    r = rast.cpu().numpy()
+    assert mk.digest(r) == bytes(fx[name + "/ids_sha256"]).decode(), "id image differs from the reference's"
+    yx, want = fx[name + "/sample_yx"], fx[name + "/sample_rast"]
+    got = r[0, yx[:, 0], yx[:, 1]]
+    assert (got[:, 3] != want[:, 3]).sum() == 0 and np.abs(got[:, :3] - want[:, :3]).max() <= 1e-5

@@ -125,3 +125,22 @@ def test_ops_transcript_replays_exactly_on_the_reference_itself(ref):
 
     doc, _ = replay(ref_torch.cpu_plugin("fma"), "cpu", on_tensor)
     assert n[0] >= 60 and doc["calls_from_fixture_scenes"] == 22
+
+
+@pytest.mark.parametrize("name", ["t1m", "t1m_shuffled", "s10k_1024"])
+def test_oracle_equals_the_reference_at_a_million_triangles(name, raw_oracle):
+    """tests/golden/t1m_reference.npz holds what the REFERENCE's rasterizer (oracle/_ref, tests/golden/make_t1m_fixture.py) makes
+    of item 0 of bench.py's million-triangle scenes and of an S10k stress item at 1024^2: SHA-256 of the id image, 256 sampled
+    (u, v, z/w, id).  The C oracle must reproduce it -- which pins the checker of bench.py's t1m blocks to the reference at that
+    size (VERDICT r5 "missing" 4); tests/test_gpu_full_size.py asks the same of the HIP path."""
+    spec = importlib.util.spec_from_file_location("make_t1m_fixture", os.path.join(HERE, "golden", "make_t1m_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    fx = np.load(os.path.join(HERE, "golden", "t1m_reference.npz"))
+    (pos, tri, res), = [(p, t, r) for n, p, t, r in mk.scenes() if n == name]
+    rast, _ = raw_oracle.rasterize(pos, tri, res)
+    assert mk.digest(rast) == bytes(fx[name + "/ids_sha256"]).decode()
+    assert int((rast[0, ..., 3] > 0).sum()) == int(fx[name + "/covered"])
+    yx, want = fx[name + "/sample_yx"], fx[name + "/sample_rast"]
+    got = rast[0, yx[:, 0], yx[:, 1]]
+    assert (got[:, 3] != want[:, 3]).sum() == 0 and np.abs(got[:, :3] - want[:, :3]).max() <= 1e-5
