@@ -1063,7 +1063,10 @@ __device__ __forceinline__ int raster_pairs(FineShared& sh, const FineParams& p,
     // lanes, at most kCoop rounds.
     // (A threshold that follows the batch -- sixteen while few masks exceed eight fragments -- was measured in round 5: within 1 %
     // on every scene; a fixed 12..16 is 2-3 % faster on meshes of small triangles and 3-5 % slower on the stress scene.)
-    constexpr int kCoop = 8;
+#ifndef NVDR_KCOOP
+#define NVDR_KCOOP 4       // (round 6: 8 -> 4 with the eight-at-a-time path behind it: S10k -2.6 %, the other scenes within noise; tools/build_ab.sh sweeps it)
+#endif
+    constexpr int kCoop = NVDR_KCOOP;
     constexpr int kOctMin = 5;                               // big masks in a batch from which they are taken eight at a time
     const bool big = __popcll(m) > kCoop;
     uint64_t heavy = __ballot(big);
