@@ -580,7 +580,9 @@ class Job:
                 # (tests/test_reference_fixture.py)
                 chk, chk_name = oracle, "oracle"
             # (the reference under its CPU shim renders ~1.9 Mpix/s: eight items of the benchmark mesh are a few seconds)
-            ns = 1 if big else min(8 if self.scene_name == "m10k" else 2, self.N)
+            # the headline workload itself: EVERY item of its batch against the reference (64 items = 16.8 Mpix: half a minute of
+            # emulation); config 4's 256 items and the regimes: a sample
+            ns = 1 if big else min((64 if self.name == "ch" else 8) if self.scene_name == "m10k" else 2, self.N)
             ro, _ = chk.rasterize(sc["pos"][:ns], sc["tri"], (RES, RES))
             Gs = self.G[:ns].cpu().numpy()
             ga_o, gr_o, _ = chk.interpolate_grad(sc["attr"], ro, sc["tri"], Gs)
@@ -629,7 +631,7 @@ class Job:
         # four-op chain, one item at the config's own resolution and texture size: every op against the reference ON THE INPUTS
         # THE HIP PATH GAVE IT (oracle/chain.py explains why a chain through a texture is not judged end to end)
         from oracle.chain import four_op_chain
-        nc = min(2, self.N)
+        nc = min(4, self.N)
         res = four_op_chain(dr, self.ctx, self.topo, chk, sc["pos"][:nc], sc["tri"], sc["uv"], self.tex_np, self.G[:nc], (RES, RES), dev=dev)
         res.update({"against": chk_name, "items": nc, "resolution": [RES, RES], "texture": list(self.tex_np.shape[1:3]), "bar": PARITY_BAR,
                     "compared": "each op on identical inputs (the HIP path's own intermediate tensors)"})
