@@ -263,3 +263,90 @@ def test_the_step_captures_into_a_graph_and_replays(dr, oracle):
     within("graph replay: out", _np(out), oo, ATOL)
     within("graph replay: g_attr", _np(attr.grad), ga, grad_tol(ga)); within("graph replay: g_pos", _np(pos.grad), gp, grad_tol(gp))
     assert ctx.cpp_wrapper.host_state(_capi.host()).captured
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_graphs_compiled_layer_equals_python_layer(dr, seed):
+    """Property test across the two host layers: a random op graph over one rasterization -- plain / differentiated / listed
+    interpolations (one or two of them), texture, antialias, a user-made consumer of rast, hooks, grad_db on or off, backward() or
+    autograd.grad() over a random subset of the inputs -- gives bit-identical forward values and gradients equal to the
+    summation-order bar on both layers (the Python layer is the one the earlier rounds' parity tests pinned to the reference)."""
+    rng = np.random.default_rng(4200 + seed)
+    n = int(rng.integers(1, 4))
+    res = (int(rng.integers(5, 20)) * 8 + int(rng.integers(0, 8)), int(rng.integers(5, 20)) * 8 + int(rng.integers(0, 8)))
+    b = m10k_batch(n, seed=int(rng.integers(1, 1000)), nx=int(rng.integers(4, 20)), ny=int(rng.integers(3, 12)))
+    V = b["pos"].shape[1]
+    A = int(rng.integers(1, 6))
+    attr_np = rng.normal(size=(V, A) if rng.uniform() < 0.5 else (n, V, A)).astype(np.float32)
+    uv_np = rng.uniform(0, 1, size=(V, 2)).astype(np.float32)
+    tex_np = rng.uniform(size=(1, 32, 64, 3)).astype(np.float32)
+    opt = dict(grad_db=bool(rng.uniform() < 0.7), da=str(rng.choice(["none", "all", "list"])), second=bool(rng.uniform() < 0.4),
+               texture=bool(rng.uniform() < 0.6), antialias=bool(rng.uniform() < 0.6), mask=bool(rng.uniform() < 0.4),
+               hook=str(rng.choice(["none", "none", "rast", "out"])), mode=str(rng.choice(["backward", "backward", "grad_subset"])))
+    diff = None if opt["da"] == "none" else "all" if opt["da"] == "all" else [int(x) for x in rng.integers(-A, A, size=int(rng.integers(1, 4)))]
+    G = {}
+
+    def upstream(name, t):
+        if name not in G:
+            G[name] = rng.normal(size=tuple(t.shape)).astype(np.float32)
+        return _t(G[name])
+
+    def run(layer):
+        _plugin.set_host_layer(layer)
+        try:
+            ctx = dr.RasterizeCudaContext()
+            pos, attr, uva, tex, tri = _t(b["pos"], True), _t(attr_np, True), _t(uv_np, True), _t(tex_np, True), _t(b["tri"])
+            rast, rast_db = dr.rasterize(ctx, pos, tri, res, grad_db=opt["grad_db"])
+            fwd, outs = [rast, rast_db], []
+            o, oda = dr.interpolate(attr, rast, tri, rast_db=rast_db if diff is not None else None, diff_attrs=diff)
+            fwd += [o, oda]
+            outs.append(("o", o))
+            if oda.numel():
+                outs.append(("oda", oda))
+            if opt["hook"] == "rast":
+                rast.register_hook(lambda g: g * 1.0)
+            if opt["hook"] == "out":
+                o.register_hook(lambda g: g * 0.5)
+            if opt["second"] or opt["texture"]:
+                uv, uvda = dr.interpolate(uva, rast, tri, rast_db=rast_db, diff_attrs="all")
+                fwd += [uv, uvda]
+                if opt["texture"]:
+                    col = dr.texture(tex, uv, uvda, filter_mode="linear-mipmap-linear")
+                    fwd.append(col)
+                    if opt["antialias"]:
+                        col = dr.antialias(col, rast, pos, tri)
+                        fwd.append(col)
+                    outs.append(("col", col))
+                else:
+                    outs += [("uv", uv), ("uvda", uvda)]
+            elif opt["antialias"] and A >= 1:
+                aa = dr.antialias(o, rast, pos, tri)
+                fwd.append(aa)
+                outs.append(("aa", aa))
+            if opt["mask"]:
+                outs.append(("mask", rast[..., :2] * rast_db[..., 1:3]))
+            tensors = [t for _, t in outs]
+            grads = [upstream(k, t) for k, t in outs]
+            leaves = [pos, attr, uva, tex]
+            if opt["mode"] == "backward":
+                torch.autograd.backward(tensors, grads)
+                got = [x.grad for x in leaves]
+            else:
+                pick = [x for k, x in enumerate(leaves) if asked[k]]
+                it = iter(torch.autograd.grad(tensors, pick, grads, allow_unused=True))
+                got = [next(it) if asked[k] else None for k in range(len(leaves))]
+            torch.cuda.synchronize()
+            return [_np(f) for f in fwd], [None if g is None else _np(g) for g in got], (pos, attr, uva, tex)
+        finally:
+            _plugin.set_host_layer("compiled")
+
+    asked = [True] + [bool(rng.uniform() < 0.5) for _ in range(3)]             # which of (pos, attr, uva, tex) autograd.grad asks for
+    f_c, g_c, _ = run("compiled")
+    f_p, g_p, _ = run("python")
+    assert len(f_c) == len(f_p)
+    for a, p in zip(f_c, f_p):
+        assert np.array_equal(a, p), opt
+    for k, (a, p) in enumerate(zip(g_c, g_p)):
+        assert (a is None) == (p is None), (opt, k)
+        if a is not None:
+            within("random graph %s leaf %d" % (opt["mode"], k), a, p, 2 * grad_tol(p))
