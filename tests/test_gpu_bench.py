@@ -41,7 +41,7 @@ def test_default_line_contract():
     assert ln["cpu_baseline"]["cpu"] and ln["cpu_baseline"]["cores"] >= 1 and "bar" in ln["parity"]
     assert all(v[1] is None or v[1] <= 1.0 for v in ln["kernels"].values())           # no bandwidth above the peak in the line
     assert ln["value_literal_step"] > 0 and ln["ms_literal_step"] >= 0.5 * ln["ms_per_step"]          # (batch 8 is host-bound: both are the host's time)
-    assert 0 < j["roofline"]["frac_required"] <= j["roofline"]["frac"] + 1e-9
+    assert 0 < j["roofline"]["frac_required"] <= j["roofline"]["frac"] + 1e-3          # (the two are rounded to different digits)
     assert j["parity"]["all_items"]["items"] == 8 and j["parity"]["all_items"]["tri_id_mismatches"] == 0
     a = j["parity"]["all_items"]
     assert a["g_attr_max_abs_err"] <= 1e-5 * max(1.0, a["g_attr_max_abs"]) and a["g_pos_max_abs_err"] <= 1e-5 * max(1.0, a["g_pos_max_abs"])

@@ -344,8 +344,12 @@ def test_random_graphs_compiled_layer_equals_python_layer(dr, seed):
     f_c, g_c, _ = run("compiled")
     f_p, g_p, _ = run("python")
     assert len(f_c) == len(f_p)
-    for a, p in zip(f_c, f_p):
-        assert np.array_equal(a, p), opt
+    for k, (a, p) in enumerate(zip(f_c, f_p)):
+        if opt["antialias"] and k == len(f_c) - 1:
+            # (a pixel blended from two sides receives two f32 atomics: their order is the hardware's, run to run)
+            within("random graph: antialiased image", a, p, ATOL)
+            continue
+        assert np.array_equal(a, p, equal_nan=True), (opt, "forward tensor %d" % k, float(np.nanmax(np.abs(a - p))), int((a != p).sum()))
     for k, (a, p) in enumerate(zip(g_c, g_p)):
         assert (a is None) == (p is None), (opt, k)
         if a is not None:
