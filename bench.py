@@ -739,6 +739,11 @@ def extra_config(name, dev, steps, warmup, windows, with_cpu, graph_too=False):
              "triangles": int(job.tri.shape[0]), "coverage": job.coverage(), "tile_coverage": job.tile_coverage(), "launch": "eager",
              "roofline": roofline, "path_hbm_frac": path_frac["alg"], "path_hbm_frac_required": path_frac["required"],
              "path_hbm_frac_counter": path_frac["counter"], "kernels": kernels, "parity": job.parity()}
+    # the rasterizer's scratch policy for this batch (include/nvdr_hip.h NVDR_OPT_SCRATCH_LIMIT_MB): worst case = no host
+    # synchronisation anywhere in the step; adaptive = a clip pool that grows on demand, one counter read back per call
+    worst = int(job.lib.nvdr_rasterize_scratch_bytes(N, int(job.tri.shape[0]), wl["res"], wl["res"]))
+    limit = int(job.lib.nvdr_get_option(job._capi.OPT_SCRATCH_LIMIT_MB))
+    block["rasterizer_scratch"] = {"worst_case_mb": worst >> 20, "limit_mb": limit, "adaptive_pool": worst > (limit << 20)}
     if with_cpu:
         cpu, cpu_ref = job.cpu_baselines(4 if job.full else 16)
         block["cpu_baseline"], block["cpu_reference"] = cpu, cpu_ref
@@ -1113,6 +1118,8 @@ def compact_config(c):
            "dom": [rf["kernel"], _r(rf["frac"], 3), _r(rf.get("frac_required"), 3)],
            "path": [_r(c.get("path_hbm_frac"), 3), _r(c.get("path_hbm_frac_required"), 3), _r(c.get("path_hbm_frac_counter"), 3)],
            "par": compact_parity(c.get("parity"))}
+    if (c.get("rasterizer_scratch") or {}).get("adaptive_pool") is not None and c.get("batch", 0) >= 256:
+        out["adaptive_pool"] = c["rasterizer_scratch"]["adaptive_pool"]          # config 4's anchor: false = no host sync in its step
     g = c.get("hipgraph_replay")
     if g:
         out["graph_ms"] = g.get("ms_per_step", "error")

@@ -68,6 +68,7 @@ def test_default_run_carries_the_other_baseline_configs():
     c4 = cf["c4"]
     assert "error" not in c4, c4
     assert c4["batch"] == 256 and c4["ms_per_step"] > 0 and c4["parity"]["tri_id_mismatches"] == 0 and c4["parity"]["items"] == 8
+    assert c4["rasterizer_scratch"]["adaptive_pool"] is False and ln["configs"]["c4"]["adaptive_pool"] is False      # the anchor has no host sync
     assert j["parity"]["items"] == 64 and cf["c3"]["parity"]["items"] == 2         # full-size items against oracle/_ref: the whole headline batch (r05: 8)
     assert ln["configs"]["t1m"]["par"]["vs"] == "ref-fixture" and ln["configs"]["t1m"]["par"]["fx"][:2] == [1, 0]      # id image = the reference's (sha-256), sampled ids equal
     for name in ("dense", "s10k", "t1m", "t1m_shuffled"):            # the regimes the benchmark scene hides
