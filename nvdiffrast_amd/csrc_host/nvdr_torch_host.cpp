@@ -149,7 +149,8 @@ struct TileRec {
     int kind;
 };
 std::mutex g_rec_mu;
-std::unordered_map<const c10::StorageImpl*, TileRec> g_recs;
+// (never destroyed: the records hold device tensors, and static destructors run after torch has begun to take its allocator down)
+std::unordered_map<const c10::StorageImpl*, TileRec>& g_recs = *new std::unordered_map<const c10::StorageImpl*, TileRec>();
 
 bool recordable(const at::Tensor& t) { return t.defined() && t.has_storage() && !t.is_inference(); }
 
