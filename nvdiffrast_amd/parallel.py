@@ -219,13 +219,14 @@ class GatherHandle:
         return unpack_images(self.wait(), self.fmt, out)
 
 
-def start_image_gather(local, fmt="f32", n_items=None, recv=None):
+def start_image_gather(local, fmt="f32", n_items=None, recv=None, send=None):
     """Pack this rank's images and start their all-gather on the backend's own stream (ordered after the kernels that wrote
     `local`); kernels launched afterwards overlap it.  `n_items`: size of the whole batch when it was split with shard_range
     (ragged splits are padded to the largest shard); None: equal shards.  `recv`: a receive buffer of an earlier call to reuse
-    (the caller must be done with what it last held).  -> GatherHandle."""
+    (the caller must be done with what it last held); `send`: likewise a packed send buffer of a collective that has completed
+    (packed formats only) -- with both, a steady loop allocates nothing.  -> GatherHandle."""
     w = world()
-    payload = pack_images(local, fmt)
+    payload = pack_images(local, fmt, out=send)
     if _single():
         return GatherHandle(_Done(), payload, [payload.shape[0]], fmt, None)
     counts = [local.shape[0]] * w if n_items is None else [shard_range(n_items, w, r)[1] for r in range(w)]
@@ -238,7 +239,8 @@ def start_image_gather(local, fmt="f32", n_items=None, recv=None):
         recv = torch.empty(shape, dtype=payload.dtype, device=payload.device)
     payload = payload.contiguous()
     work = dist.all_gather_into_tensor(recv, payload, async_op=True)
-    return GatherHandle(work, recv, counts, fmt, payload)
+    h = GatherHandle(work, recv, counts, fmt, payload)
+    return h
 
 
 class ImageGather:
@@ -258,6 +260,7 @@ class ImageGather:
         assert fmt in FORMATS
         self.fmt, self.n_items, self.pipelined = fmt, n_items, bool(pipelined)
         self._recv = [None, None, None]
+        self._send = [None, None, None]
         self._step = 0
         self._flying = None          # the handle submit() started and nobody has collected yet
         self._previous = None        # pipelined: the handle of the step before
@@ -265,8 +268,11 @@ class ImageGather:
     def submit(self, images):
         assert self._flying is None, "ImageGather: collect() must follow every submit()"
         k = self._step % 3
-        self._flying = start_image_gather(images, self.fmt, self.n_items, self._recv[k])
+        # (buffer k's previous collective -- three submits ago -- has been waited for by the collect() after the next submit)
+        self._flying = start_image_gather(images, self.fmt, self.n_items, self._recv[k], self._send[k])
         self._recv[k] = self._flying.recv
+        if self.fmt != "f32" and self._flying._keep is not None:
+            self._send[k] = self._flying._keep
         self._step += 1
 
     def collect(self):
