@@ -911,7 +911,7 @@ struct FineParams {
 constexpr int kEarlyZTiles = 4;                          // tile bounds a wave refreshes per batch of 64 pairs once covered tiles see more pairs (k_fine)
 
 // Refresh cadence of the per-tile depth bounds (k_fine): kEarlyZTiles tiles per batch of 64 pairs once covered tiles see more
-// pairs; one after a batch that held a mask with more than eight fragments; otherwise one every kColdRefresh batches.
+// pairs; one after a batch that held a mask with more than kCoop fragments; otherwise one every kColdRefresh batches.
 constexpr int kColdRefresh = 8;
 
 struct FineShared {
