@@ -191,6 +191,7 @@ struct RasterState {
     int64_t reported_bytes = 0;
     std::map<std::pair<int64_t, int64_t>, int64_t> pools;
     at::Tensor depth, peel;
+    at::Tensor last_flags;               // tile occupancy of the most recent call's output (the plugin-level entry point attaches it to that rast)
     explicit RasterState(int idx) : device_idx(idx) {}
 
     int64_t scratch_numel() const { return scratch.defined() ? scratch.numel() : 0; }
@@ -376,6 +377,7 @@ RastPair rasterize(const std::shared_ptr<RasterState>& st, const at::Tensor& pos
     st->has_clean = true;
     st->clean_layout = layout;
     attach(out, flags, KIND_RAST);
+    st->last_flags = flags;
     g_n_fast_fwd++;
 
     if (torch::autograd::compute_requires_grad(pos)) {
@@ -792,8 +794,12 @@ struct AntialiasNode : public Node {
 };
 
 // antialias_fwd (torch_antialias.cpp:68-155).  ev_hash: the TopologyHashWrapper's table.
-std::optional<at::Tensor> antialias_op(const at::Tensor& color, const at::Tensor& rast, const at::Tensor& pos, const at::Tensor& tri,
-                                    const at::Tensor& ev_hash, double boost) {
+using AaPair = std::optional<std::tuple<at::Tensor, at::Tensor>>;
+
+// (out, work buffer), and the autograd node on `out` when `with_node`; the plugin-level entry point antialias_fwd -- which hands
+// the work buffer to ITS caller's autograd function -- takes the pair without a node.
+AaPair antialias_impl(const at::Tensor& color, const at::Tensor& rast, const at::Tensor& pos, const at::Tensor& tri,
+                      const at::Tensor& ev_hash, double boost, bool with_node) {
     if (!api.ready || g_verify.load(std::memory_order_relaxed)) return std::nullopt;
     const c10::Device dev = color.device();
     const bool instance = pos.dim() > 2;
@@ -821,7 +827,7 @@ std::optional<at::Tensor> antialias_op(const at::Tensor& color, const at::Tensor
                             flags.defined() ? flags.data_ptr<uint8_t>() : nullptr, stream_of(index_of(color))),
           "antialias_fwd");
     g_n_fast_fwd++;
-    if (torch::autograd::compute_requires_grad(color, pos)) {
+    if (with_node && torch::autograd::compute_requires_grad(color, pos)) {
         auto node = std::shared_ptr<AntialiasNode>(new AntialiasNode(), torch::autograd::deleteNode);
         node->set_next_edges(torch::autograd::collect_next_edges(color, pos));
         node->color_ = SavedVariable(color, false);
@@ -832,7 +838,18 @@ std::optional<at::Tensor> antialias_op(const at::Tensor& color, const at::Tensor
         node->boost_ = boost;
         torch::autograd::set_history(out, node);
     }
-    return out;
+    return std::make_tuple(std::move(out), std::move(work));
+}
+
+std::optional<at::Tensor> antialias_op(const at::Tensor& color, const at::Tensor& rast, const at::Tensor& pos, const at::Tensor& tri,
+                                       const at::Tensor& ev_hash, double boost) {
+    AaPair r = antialias_impl(color, rast, pos, tri, ev_hash, boost, true);
+    if (!r.has_value()) return std::nullopt;
+    return std::get<0>(*r);
+}
+
+AaPair antialias_fwd_raw(const at::Tensor& color, const at::Tensor& rast, const at::Tensor& pos, const at::Tensor& tri, const at::Tensor& ev_hash) {
+    return antialias_impl(color, rast, pos, tri, ev_hash, 1.0, false);
 }
 
 py::dict counters() {
@@ -858,6 +875,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         // the depth surfaces of the last DepthPeeler pass and the clip-pool bookkeeping, for tests and tools
         .def_property_readonly("depth", [](const RasterState& s) -> std::optional<at::Tensor> { if (!s.depth.defined()) return std::nullopt; return s.depth; })
         .def_property_readonly("peel", [](const RasterState& s) -> std::optional<at::Tensor> { if (!s.peel.defined()) return std::nullopt; return s.peel; })
+        .def_property_readonly("last_flags", [](const RasterState& s) -> std::optional<at::Tensor> { if (!s.last_flags.defined()) return std::nullopt; return s.last_flags; })
         .def("poison_scratch", [](RasterState& s, int value) { if (s.scratch.defined()) s.scratch.fill_(value); s.has_clean = false; })
         .def("set_scratch", [](RasterState& s, const at::Tensor& t) { s.scratch = t; s.has_clean = false; })
         .def("set_pool", [](RasterState& s, int64_t n, int64_t max_tri, int64_t slots) { s.pools[{n, max_tri}] = slots; })
@@ -869,6 +887,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("construct_mip", &construct_mip, py::call_guard<py::gil_scoped_release>());
     m.def("texture", &texture_op, py::call_guard<py::gil_scoped_release>());
     m.def("antialias", &antialias_op, py::call_guard<py::gil_scoped_release>());
+    m.def("antialias_fwd_raw", &antialias_fwd_raw, py::call_guard<py::gil_scoped_release>());
     m.def("attach", &attach);
     m.def("flags_of", [](const at::Tensor& t, int kind) -> std::optional<at::Tensor> {
         at::Tensor f = flags_of(t, kind);

@@ -111,6 +111,15 @@ def host_layer_name():
     return "compiled" if host_layer() is not None else "python"
 
 
+def _host_raw(fn, *args):
+    """A function of the compiled layer as a PLUGIN-level entry point: plain tensors out, no autograd node on them (the caller --
+    the reference's ops.py, a test -- brings its own autograd function; inside its forward() grad mode is off already)."""
+    if torch.is_grad_enabled():
+        with torch.no_grad():
+            return fn(*args)
+    return fn(*args)
+
+
 def _is_capturing(device):
     return torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
 
@@ -320,6 +329,19 @@ class RasterizeCRStateWrapper:
 def rasterize_fwd_cuda(state, pos, tri, resolution, ranges, peeling_idx):
     """torch_rasterize.cpp:43-166."""
     fn = "rasterize_fwd_cuda"
+    h = host_layer()
+    if h is not None and len(resolution) == 2:
+        # the ordinary case, served by the compiled layer (csrc_host/nvdr_torch_host.cpp); None: not ordinary -> everything below
+        hs = state.host_state(h)
+        served = _host_raw(h.rasterize, hs, pos, tri, int(resolution[0]), int(resolution[1]), ranges, True, int(peeling_idx))
+        if served is not None:
+            out, out_db = served
+            if peeling_idx >= 0:
+                state.depth, state.peel = hs.depth, hs.peel
+            state.last_flags = flags = hs.last_flags
+            _attach_tiles(out, flags, "rast")
+            out._nvdr_tiles.origin = _FwdOrigin(pos, tri, state, out, out_db)
+            return out, out_db
     ps, ts = pos.shape, tri.shape
     dev = pos.device
     instance_mode = len(ps) > 2
@@ -806,6 +828,14 @@ def interpolate_fwd_da(attr, rast, tri, rast_db, diff_attrs_all, diff_attrs_vec,
     """torch_interpolate.cpp:42-124."""
     fn = "interpolate_fwd_da"
     enable_da = (rast_db is not None) and (bool(diff_attrs_all) or len(diff_attrs_vec) > 0)
+    h = host_layer()
+    if h is not None and tile_flags is None:                 # (the caller leaves the flags to the records: so does the compiled layer)
+        served = _host_raw(h.interpolate, attr, rast, tri, rast_db if enable_da else None, bool(diff_attrs_all), [int(x) for x in diff_attrs_vec])
+        if served is not None:
+            org = _origin_of(rast)
+            if org is not None:
+                org.interpolations += 1
+            return served
     instance_mode = attr.dim() > 2
     dev = attr.device
     f32 = torch.float32
@@ -1205,6 +1235,15 @@ def _texture_common(fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, 
 def texture_fwd_mip(tex, uv, uv_da, mip_level_bias, mip_wrapper, mip_stack, filter_mode, boundary_mode, tile_flags=None):
     """torch_texture.cpp:174-407."""
     fn = "texture_fwd_mip"
+    h = host_layer()
+    if h is not None and tile_flags is None and len(mip_stack) == 0:
+        mw = mip_wrapper if (mip_wrapper is not None and mip_wrapper.mip is not None) else None
+        served = _host_raw(h.texture, tex, uv, uv_da if _has(uv_da) else None, mip_level_bias if _has(mip_level_bias) else None,
+                           None if mw is None else mw.mip, 0 if mw is None else int(mw.max_mip_level),
+                           [] if mw is None else [int(x) for x in mw.texture_size], False if mw is None else bool(mw.cube_mode),
+                           int(filter_mode), int(boundary_mode), _TEX_GRAD_SCRATCH)
+        if served is not None:
+            return served
     dev, enable_mip, has_uv_da, has_bias, levels, _, _ = _texture_common(
         fn, tex, uv, uv_da, mip_level_bias, mip_wrapper, list(mip_stack), filter_mode, boundary_mode, False)
     tn, th, tw, C = _tex_dims(tex, boundary_mode == _BOUNDARY_CUBE)
@@ -1347,6 +1386,11 @@ def antialias_fwd(color, rast, pos, tri, topology_hash_wrap, tile_flags=None):
     """torch_antialias.cpp:68-155 -> (out, work_buffer)."""
     fn = "antialias_fwd"
     topology_hash = topology_hash_wrap.ev_hash
+    h = host_layer()
+    if h is not None and tile_flags is None and topology_hash is not None:
+        served = h.antialias_fwd_raw(color, rast, pos, tri, topology_hash)
+        if served is not None:
+            return served                                        # (out, work_buffer)
     dev = _check_device(fn, color=color, rast=rast, pos=pos, tri=tri, topology_hash=topology_hash)
     _check_contiguous(fn, color=color, rast=rast, pos=pos, tri=tri, topology_hash=topology_hash)
     _check_f32(fn, color=color, rast=rast, pos=pos)
